@@ -1,0 +1,229 @@
+/*
+ * unet_tm_hip.h -- C ABI of libunet_tm_hip.so: the U-Net traffic-matrix hot path
+ * (forward, backward, loss, optimiser step) as hand-written gfx950 HIP kernels.
+ *
+ * Every entry point takes raw device pointers, plain ints and a hipStream_t (passed
+ * as void*).  The caller owns all memory: outputs and workspaces are caller-allocated,
+ * nothing is retained after a call returns, nothing is freed by the library.  Work is
+ * enqueued on the given stream; no entry point synchronises.  The return value is 0 on
+ * success, a negative MI_E* code for an argument error, or a positive hipError_t.
+ * mi_last_error() returns a thread-local description of the last failure.
+ *
+ * "Reference" below is VoVanVi/Unet-based-Network-Traffic-Prediction; each entry point
+ * names the reference call site whose arithmetic it replaces.
+ *
+ * Activation layout.  Inside the library activations are NHWC ("pixel-major"): element
+ * (b, y, x, c) of a view lives at  base[((b*H + y)*W + x) * cstride + coff + c].
+ * cstride/coff let several tensors share one buffer (the skip and the upsampled half of
+ * a decoder input are two channel ranges of one allocation, which is how the concat of
+ * models/unet2d.py:86 costs no copy).  Channel counts are padded to multiples of 16;
+ * padding channels hold zeros.  dtype selects the storage/compute type of activations
+ * and packed weights: MI_F32 (fp32 storage, exact-fp32 MFMA) or MI_BF16 (bf16 storage,
+ * bf16 MFMA, fp32 accumulate).  Parameters, parameter gradients, the loss and the
+ * network input/output are always fp32 in the reference's NCHW / (Cout,Cin,kh,kw) layout.
+ */
+#ifndef UNET_TM_HIP_H
+#define UNET_TM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_F32 0
+#define MI_BF16 1
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define MI_ESIZE (-2)    /* buffer / workspace too small */
+#define MI_ESTATE (-3)   /* call out of order (e.g. backward before forward) */
+
+typedef void* mi_stream;               /* hipStream_t */
+typedef struct mi_unet_plan mi_unet_plan;
+
+int mi_version(void);
+const char* mi_last_error(void);
+/* Round a channel count up to the library's padding granule (16). */
+int mi_pad_channels(int c);
+
+/* ------------------------------------------------------------------ layout helpers */
+/* fp32 NCHW (B,C,H,W) -> NHWC view of `dtype` with C padded (pad channels zeroed).
+ * Replaces nothing in the reference (its tensors stay NCHW, dataset.py:221-223);
+ * it is the entry of the network input into the library's layout. */
+int mi_nchw_to_nhwc(const float* src, void* dst, int dst_cstride, int dst_coff,
+                    int B, int C, int H, int W, int dtype, mi_stream s);
+/* NHWC view -> fp32 NCHW (first C channels). */
+int mi_nhwc_to_nchw(const void* src, int src_cstride, int src_coff, float* dst,
+                    int B, int C, int H, int W, int dtype, mi_stream s);
+
+/* ------------------------------------------------------------------ weight packing */
+/* nn.Conv2d weight (Cout,Cin,3,3) fp32 -> K-major packed operands of `dtype`:
+ *   wfwd [Npad][Kp]  Npad=pad(Cout), k = tap*Cpad_in + pos(ci)           (forward)
+ *   wbwd [Cpad_in][Kp2] k = (8-tap)*Npad + co   (180-degree rotated, for dgrad)
+ * pos(ci) = ci for ci < split, pad(split) + (ci-split) otherwise: `split` is the
+ * channel count of the first concat operand (0 = no concat).  Kp/Kp2 = K rounded up
+ * to a multiple of 64 elements.  Either output may be NULL. */
+int mi_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split,
+                    int dtype, mi_stream s);
+/* nn.ConvTranspose2d weight (Cin,Cout,2,2) fp32 ->
+ *   wfwd [4*Npad][Kp]   row = (a*2+b)*Npad + co, k = ci                   (forward)
+ *   wbwd [Cpad_in][Kp2] k = (a*2+b)*Npad + co                             (dgrad)  */
+int mi_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout,
+                     int dtype, mi_stream s);
+size_t mi_packed_conv3x3_bytes(int Cout, int Cin, int split, int dtype, int which /*0 fwd,1 bwd*/);
+size_t mi_packed_convt2x2_bytes(int Cin, int Cout, int dtype, int which);
+
+/* ------------------------------------------------------------------ A1: 3x3 conv + ReLU */
+/* y = relu(conv3x3(x, W, pad 1) + b): nn.Conv2d(k=3,padding=1)+nn.ReLU,
+ * models/unet2d.py:28-31, :38-41, :51-54.  Implicit GEMM on MFMA.  relu=0 omits the
+ * activation.  Cin/Cout are the logical channel counts; x carries pad(Cin) (+ concat
+ * padding when split>0), y receives pad(Cout) channels. */
+int mi_conv3x3_relu_fwd(const void* x, int x_cstride, int x_coff, const void* wfwd, const float* bias,
+                        void* y, int y_cstride, int y_coff,
+                        int B, int H, int W, int Cin, int split, int Cout, int relu, int dtype, mi_stream s);
+/* dx = conv3x3(dy, rot180(W)) [* (mask > 0)]: the autograd backward of the same
+ * layers w.r.t. their input.  dy must already be the gradient w.r.t. the conv's
+ * pre-activation output (ReLU mask applied by its producer).  If mask != NULL the
+ * result is multiplied by (mask > 0) element-wise: that is the ReLU backward of the
+ * PRECEDING layer (nn.ReLU(inplace=True) saves its output), fused here. */
+int mi_conv3x3_dgrad(const void* dy, int dy_cstride, int dy_coff, const void* wbwd,
+                     void* dx, int dx_cstride, int dx_coff,
+                     const void* mask, int mask_cstride, int mask_coff,
+                     int B, int H, int W, int Cin, int split, int Cout, int dtype, mi_stream s);
+/* dW (Cout,Cin,3,3) and db (Cout) in fp32:  dW = alpha * sum_pixels(...) + beta * dW.
+ * Deterministic: pixel-range partials in `ws`, summed in a fixed order.
+ * ws must hold mi_conv3x3_wgrad_ws_bytes() bytes. */
+int mi_conv3x3_wgrad(const void* x, int x_cstride, int x_coff,
+                     const void* dy, int dy_cstride, int dy_coff,
+                     float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes,
+                     int B, int H, int W, int Cin, int split, int Cout, int dtype, mi_stream s);
+size_t mi_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int split, int Cout, int dtype);
+
+/* ------------------------------------------------------------------ A2: 2x2 max-pool */
+/* nn.MaxPool2d(2,2), models/unet2d.py:22/:68.  Output is (B, H/2, W/2, C) (floor). */
+int mi_maxpool2_fwd(const void* x, int x_cstride, int x_coff, void* y, int y_cstride, int y_coff,
+                    int B, int H, int W, int C, int dtype, mi_stream s);
+/* Backward of the pool fused with what surrounds it in the U-Net:
+ *   dx = (route(dy_pool) + dskip) * (x > 0)
+ * route() sends each pooled gradient to the FIRST maximum of its window in row-major
+ * order (PyTorch's tie rule).  dskip (may be NULL) is the gradient arriving at the same
+ * tensor through the skip connection (models/unet2d.py:67/:86); relu_mask!=0 applies
+ * the ReLU backward of the conv that produced x.  dx may alias dskip. */
+int mi_maxpool2_bwd(const void* x, int x_cstride, int x_coff, const void* dy_pool, int dyp_cstride, int dyp_coff,
+                    const void* dskip, int ds_cstride, int ds_coff, void* dx, int dx_cstride, int dx_coff,
+                    int B, int H, int W, int C, int relu_mask, int dtype, mi_stream s);
+
+/* ------------------------------------------------------------------ A3: 2x2 stride-2 transposed conv */
+/* nn.ConvTranspose2d(Cin,Cout,2,2), models/unet2d.py:46-48/:77.  x is (B,H,W,Cin),
+ * y is (B,2H,2W,Cout) written through the (cstride,coff) view, i.e. straight into the
+ * second half of the decoder's concat buffer. */
+int mi_convt2x2_fwd(const void* x, int x_cstride, int x_coff, const void* wfwd, const float* bias,
+                    void* y, int y_cstride, int y_coff, int B, int H, int W, int Cin, int Cout,
+                    int dtype, mi_stream s);
+int mi_convt2x2_dgrad(const void* dy, int dy_cstride, int dy_coff, const void* wbwd,
+                      void* dx, int dx_cstride, int dx_coff,
+                      const void* mask, int mask_cstride, int mask_coff,
+                      int B, int H, int W, int Cin, int Cout, int dtype, mi_stream s);
+int mi_convt2x2_wgrad(const void* x, int x_cstride, int x_coff, const void* dy, int dy_cstride, int dy_coff,
+                      float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes,
+                      int B, int H, int W, int Cin, int Cout, int dtype, mi_stream s);
+size_t mi_convt2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dtype);
+
+/* ------------------------------------------------------------------ A5: 1x1 head */
+/* nn.Conv2d(features[0], out_channels, 1), models/unet2d.py:59/:89.  x NHWC view,
+ * pred fp32 NCHW (B,Cout,H,W).  w is the fp32 parameter (Cout,Cin[,1,1]) itself. */
+int mi_conv1x1_head_fwd(const void* x, int x_cstride, int x_coff, const float* w, const float* bias,
+                        float* pred, int B, int H, int W, int Cin, int Cout, int dtype, mi_stream s);
+/* dx = (W^T dpred) * (x > 0) (relu_mask), dW = alpha*sum + beta*dW, db likewise. */
+int mi_conv1x1_head_bwd(const void* x, int x_cstride, int x_coff, const float* w, const float* dpred,
+                        void* dx, int dx_cstride, int dx_coff, float* dW, float* db,
+                        float alpha, float beta, void* ws, size_t ws_bytes,
+                        int B, int H, int W, int Cin, int Cout, int relu_mask, int dtype, mi_stream s);
+size_t mi_conv1x1_head_ws_bytes(int Cin, int Cout);
+
+/* ------------------------------------------------------------------ A6: MSE loss */
+/* nn.MSELoss() (train.py:498/:387) and the sums of test.py:39-43 in one pass.
+ * out3 (device, 3 floats) = { mean((pred-y)^2), sum|pred-y|, sum (pred-y)^2 }.
+ * If dpred != NULL also writes dpred = gscale * 2*(pred-y)/n  (gscale_dev, if not NULL,
+ * is a device scalar multiplied in: the upstream gradient of the loss).
+ * ws: mi_mse_ws_bytes(n). Deterministic two-pass reduction. */
+int mi_mse_fwd_bwd(const float* pred, const float* target, int64_t n, float* out3,
+                   float* dpred, float gscale, const float* gscale_dev, void* ws, size_t ws_bytes, mi_stream s);
+size_t mi_mse_ws_bytes(int64_t n);
+
+/* ------------------------------------------------------------------ A8: bilinear resize */
+/* F.interpolate(mode="bilinear", align_corners=False), models/unet2d.py:81-84, :92-100.
+ * Generic strided 4-D views: element (b,c,y,x) at base[b*sb + c*sc + y*sy + x*sx].
+ * src_dtype/dst_dtype are MI_F32/MI_BF16.  The backward is a gather (deterministic). */
+int mi_bilinear_fwd(const void* src, int64_t ssb, int64_t ssc, int64_t ssy, int64_t ssx, int src_dtype,
+                    void* dst, int64_t dsb, int64_t dsc, int64_t dsy, int64_t dsx, int dst_dtype,
+                    int B, int C, int Hin, int Win, int Hout, int Wout, mi_stream s);
+int mi_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy, int64_t osx, int dout_dtype,
+                    void* din, int64_t isb, int64_t isc, int64_t isy, int64_t isx, int din_dtype,
+                    int B, int C, int Hin, int Win, int Hout, int Wout, mi_stream s);
+
+/* ------------------------------------------------------------------ F1: Adam */
+/* torch.optim.Adam(lr) step (train.py:497) over one flat fp32 range: default betas
+ * handling, no weight decay / amsgrad.  step is the 1-based step count.
+ * grad_scale multiplies the gradient first (1/world_size in data-parallel runs). */
+int mi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, float grad_scale, mi_stream s);
+
+/* ------------------------------------------------------------------ A7: whole-network plan */
+/* The orchestration of UNet.forward (models/unet2d.py:61-102) and of its autograd
+ * backward as one launch sequence per call.  A plan is immutable shape metadata. */
+typedef struct mi_unet_desc {
+  int in_channels, out_channels;
+  int n_levels;            /* len(features), 1..8 */
+  int features[8];         /* must double per level, as the reference requires */
+  int batch, height, width;
+  int out_h, out_w;        /* forced output size (models/unet2d.py:92-100) or 0,0 */
+  int dtype;               /* MI_F32 / MI_BF16 */
+  int need_input_grad;     /* also compute d(loss)/d(x) */
+} mi_unet_desc;
+
+int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out);
+void mi_unet_plan_destroy(mi_unet_plan* plan);
+size_t mi_unet_plan_workspace_bytes(const mi_unet_plan* plan);
+/* Flat fp32 parameter buffer: parameters in construction order (downs, bottleneck,
+ * ups, final_conv), each starting at a multiple of 64 elements. */
+int64_t mi_unet_plan_flat_elems(const mi_unet_plan* plan);
+int mi_unet_plan_num_params(const mi_unet_plan* plan);
+int mi_unet_plan_param_info(const mi_unet_plan* plan, int i, char* name, int name_cap,
+                            int64_t* flat_offset, int64_t shape[4], int* ndim);
+/* Named intermediate tensors inside the workspace (activations "act.*", gradients
+ * "grad.*"), for per-layer parity checks.  layout: 0 = NHWC of plan dtype, 1 = fp32 NCHW. */
+int mi_unet_plan_num_tensors(const mi_unet_plan* plan);
+int mi_unet_plan_tensor_info(const mi_unet_plan* plan, int i, char* name, int name_cap,
+                             int64_t* ws_offset_bytes, int dims[4] /*B,H,W,C*/, int* cstride,
+                             int* coff, int* layout);
+/* Backward runs in segments so a caller can start reducing a gradient range while the
+ * rest of backward is still running.  Segment s covers flat range [lo,hi); segments
+ * are numbered in execution order (head first) and their ranges descend. */
+int mi_unet_plan_num_segments(const mi_unet_plan* plan);
+int mi_unet_plan_segment_range(const mi_unet_plan* plan, int seg, int64_t* lo, int64_t* hi);
+
+#define MI_FWD_REPACK 1      /* parameters changed since the last forward: repack weights */
+#define MI_FWD_TRAIN 2       /* keep what backward needs (also packs dgrad weights) */
+int mi_unet_forward(mi_unet_plan* plan, const float* x_nchw, const float* params_flat, void* ws,
+                    size_t ws_bytes, float* pred_nchw, int flags, mi_stream s);
+/* grads_flat = alpha * dL/dparams + beta * grads_flat over segments [seg_lo, seg_hi). */
+int mi_unet_backward(mi_unet_plan* plan, const float* dpred_nchw, const float* params_flat, void* ws,
+                     size_t ws_bytes, float* grads_flat, float alpha, float beta, int seg_lo, int seg_hi,
+                     float* dx_nchw, mi_stream s);
+
+/* Per-launch timing: when enabled, forward/backward bracket every kernel launch with
+ * HIP events on the launch stream.  mi_unet_profile_read synchronises those events and
+ * returns, for launch i, the kernel name, a layer label, algorithmic FLOPs and bytes,
+ * and the elapsed milliseconds. */
+int mi_unet_profile_enable(mi_unet_plan* plan, int on);
+int mi_unet_profile_count(const mi_unet_plan* plan);
+int mi_unet_profile_read(mi_unet_plan* plan, int i, char* kernel, int kcap, char* label, int lcap,
+                         double* flops, double* bytes, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_TM_HIP_H */

@@ -1,0 +1,276 @@
+"""Whole-network parity of the HIP U-Net against the golden fixtures recorded from the
+reference and against the CPU oracle.
+
+Tolerances (relative L2 unless stated), grounded in the measured fp32-vs-fp64 and
+bf16-autocast-vs-fp64 noise floors of this network:
+  fp32 kernels : layer outputs <= 1e-5, gradients <= 5e-5, 20-step loss curve rel <= 1e-5
+  bf16 kernels : layer outputs <= 1e-2, gradients <= 5e-2 median / 1.5e-1 worst tensor,
+                 20-step loss curve rel <= 2e-3
+"""
+import types
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BAR = {
+    "fp32": dict(out=1e-5, grad=5e-5, grad_med=5e-5, loss=1e-5),
+    "bf16": dict(out=1e-2, grad=1.5e-1, grad_med=5e-2, loss=2e-3),
+}
+
+
+@pytest.fixture(scope="module")
+def ua():
+    import unet_amd
+    unet_amd.lib()
+    return unet_amd
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def meta(g):
+    feats = tuple(int(v) for v in g["meta.features"])
+    osz = tuple(int(v) for v in g["meta.out_size"])
+    return int(g["meta.cin"]), int(g["meta.cout"]), feats, (None if osz[0] < 0 else osz)
+
+
+def model_from_fixture(ua, g, dtype):
+    cin, cout, feats, osz = meta(g)
+    model = ua.UNet(cin, cout, feats, out_size=osz, compute_dtype=dtype)
+    state = OrderedDict((k[6:], torch.from_numpy(g[k])) for k in g.files if k.startswith("param."))
+    model.load_state_dict(state, strict=True)          # test.py:135 path
+    return model.to("cuda"), state
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["small4", "small5", "odd"])
+def test_per_layer_outputs_and_gradients(ua, golden, name, dtype):
+    g = golden(name)
+    bar = BAR[dtype]
+    model, state = model_from_fixture(ua, g, dtype)
+    X = torch.from_numpy(g["X"]).cuda().requires_grad_(True)
+    Y = torch.from_numpy(g["Y"]).cuda()
+    pred = model(X)
+    loss = ua.MSELoss()(pred, Y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(pred.detach().cpu(), torch.from_numpy(g["pred"])) < bar["out"]
+    assert abs(loss.item() - float(g["loss0"])) <= bar["out"] * abs(float(g["loss0"]))
+    names = model.last_plan.tensors()
+    n_act = n_grad = 0
+    worst = {}
+    for k in g.files:
+        if k.startswith("act."):
+            if k in names:
+                e = rel(model.workspace_tensor(k).cpu(), torch.from_numpy(g[k]))
+                assert e < bar["out"], (k, e)
+                n_act += 1
+            else:
+                assert k == "act.final_conv" and "act.final_conv" not in names   # head output is `pred` itself
+        elif k.startswith("actgrad."):
+            lname = k[len("actgrad."):]
+            ref = torch.from_numpy(g[k])
+            if lname == "final_conv":
+                continue
+            post_relu = not lname.startswith("pool.") and (lname.endswith(".1") or lname.endswith(".3"))
+            if post_relu:
+                # the workspace holds the gradient w.r.t. the conv's pre-activation:
+                # reference gradient of the post-ReLU tensor times the ReLU mask
+                ref = ref * (torch.from_numpy(g["act." + lname]) > 0)
+            got = model.workspace_tensor("grad." + lname).cpu()
+            if dtype == "bf16" and post_relu:
+                # an activation that rounds to zero in bf16 flips its mask; compare where both agree it is on
+                on = (model.workspace_tensor("act." + lname).cpu() > 0) == (torch.from_numpy(g["act." + lname]) > 0)
+                got, ref = got * on, ref * on
+            e = rel(got, ref)
+            worst[lname] = e
+            n_grad += 1
+    assert n_act >= 26 and n_grad >= 26
+    assert max(worst.values()) < bar["grad"], sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    if dtype == "fp32":
+        assert float(np.median(list(worst.values()))) < bar["grad_med"]
+    # (bf16: the median bar is stated for PARAMETER gradients.  Activation gradients of these
+    # reduced-width nets sit at 4-7 % for this path and at 5-14 % for torch's own CPU
+    # autocast(bf16) of the oracle on the same fixture -- scripts/diag_bf16.py prints both --
+    # so only the worst-tensor bar applies to them.)
+    errs = {k: rel(p.grad.cpu(), torch.from_numpy(g["grad." + k])) for k, p in model.named_parameters()}
+    assert max(errs.values()) < bar["grad"], sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert float(np.median(list(errs.values()))) < bar["grad_med"]
+    assert rel(X.grad.cpu(), torch.from_numpy(g["dX"])) < bar["grad"]
+    if name == "odd":
+        assert "act.align.0" in names and tuple(pred.shape[2:]) == (15, 24)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["small4", "odd", "cfg1_full", "cfg2_b32"])
+def test_loss_after_n_adam_steps(ua, golden, name, dtype):
+    """The loop body of train.py:382-393 (forward, MSE, zero_grad, backward, Adam step) for
+    20 steps on one fixed batch; the loss curve must track the reference's."""
+    g = golden(name)
+    cin, cout, feats, osz = meta(g)
+    b = int(g["meta.batch"]); h, w = (int(v) for v in g["meta.hw"])
+    torch.manual_seed(0)
+    model = ua.UNet(cin, cout, feats, out_size=osz, compute_dtype=dtype).to("cuda")
+    oh, ow = osz if osz else (h, w)
+    gen = torch.Generator().manual_seed(1)
+    X = torch.rand(b, cin, h, w, generator=gen).cuda()
+    Y = torch.rand(b, cout, oh, ow, generator=gen).cuda()
+    opt = ua.FusedAdam(model.parameters(), lr=1e-4, model=model)
+    crit = ua.MSELoss()
+    losses = []
+    model.train()
+    for _ in range(len(g["losses"])):
+        pred = model(X)
+        loss = crit(pred, Y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    ref = np.asarray(g["losses"])
+    dev = np.max(np.abs(np.asarray(losses) - ref) / np.abs(ref))
+    assert dev < BAR[dtype]["loss"], (dev, losses[:3], ref[:3])
+    model.eval()
+    with torch.no_grad():
+        sums, n = ua.eval_sums(model(X), Y)          # test.py:39-43
+    sums = sums.cpu()
+    tol = 50 * BAR[dtype]["loss"]
+    assert n == int(g["eval.numel"])
+    assert abs(sums[0].item() - float(g["eval.abs_sum"])) <= tol * float(g["eval.abs_sum"])
+    assert abs(sums[1].item() - float(g["eval.sq_sum"])) <= tol * float(g["eval.sq_sum"])
+
+
+def test_unchanged_reference_loop_with_stock_optimizer_and_loss(ua, golden):
+    """torch.optim.Adam + nn.MSELoss exactly as train.py:497-498 builds them, driving the
+    HIP module through autograd."""
+    g = golden("small4")
+    cin, cout, feats, osz = meta(g)
+    cfg = types.SimpleNamespace(model_type="UNet", in_channels=cin, out_channels=cout, unet_features=feats,
+                                compute_dtype="fp32")
+    torch.manual_seed(0)
+    model = ua.build_model_from_cfg(cfg).to("cuda:0")        # train.py:495, config.py:64
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
+    criterion = torch.nn.MSELoss()
+    X, Y = torch.from_numpy(g["X"]).to("cuda:0"), torch.from_numpy(g["Y"]).to("cuda:0")
+    losses = []
+    for _ in range(len(g["losses"])):
+        pred = model(X)
+        loss = criterion(pred, Y)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.item())
+    ref = np.asarray(g["losses"])
+    assert np.max(np.abs(np.asarray(losses) - ref) / np.abs(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["cfg1_full", "cfg2_b32"])
+def test_full_width_samples_and_norms(ua, golden, name):
+    g = golden(name)
+    cin, cout, feats, osz = meta(g)
+    b = int(g["meta.batch"]); h, w = (int(v) for v in g["meta.hw"])
+    torch.manual_seed(0)
+    model = ua.UNet(cin, cout, feats, compute_dtype="fp32")
+    for k, v in model.state_dict().items():                 # same-seed init == reference init
+        assert v.double().norm().item() == float(g["paramnorm." + k])
+    model = model.to("cuda")
+    X, Y = O.synthetic_batch(b, cin, cout, h, w)
+    pred = model(X.cuda())
+    loss = ua.MSELoss()(pred, Y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss0"])) <= 1e-5 * float(g["loss0"])
+    pv = pred.detach().cpu().flatten()[torch.from_numpy(g["predidx"])]
+    assert rel(pv, torch.from_numpy(g["predval"])) < 1e-5
+    assert abs(pred.detach().double().norm().item() - float(g["prednorm"])) <= 1e-5 * float(g["prednorm"])
+    for k, p in model.named_parameters():
+        gn = float(g["gradnorm." + k])
+        assert abs(p.grad.double().norm().item() - gn) <= 5e-5 * gn, k
+        got = p.grad.cpu().flatten()[torch.from_numpy(g["gradidx." + k])]
+        ref = torch.from_numpy(g["gradval." + k])
+        assert (got - ref).abs().max().item() <= 5e-5 * gn / np.sqrt(p.numel()) * 30 + 1e-12, k
+    for k in g.files:
+        if k.startswith("actnorm.") and ("act." + k[8:]) in model.last_plan.tensors():
+            t = model.workspace_tensor("act." + k[8:]).cpu()
+            assert abs(t.double().norm().item() - float(g[k])) <= 1e-5 * float(g[k]), k
+            idx = torch.from_numpy(g["actidx." + k[8:]])
+            assert rel(t.flatten()[idx], torch.from_numpy(g["actval." + k[8:]])) < 1e-4, k
+
+
+def test_state_dict_interchange_and_eval(ua):
+    torch.manual_seed(3)
+    model = ua.UNet(12, 1, (8, 16, 32, 64), compute_dtype="fp32")
+    ref_state = O.init_state_dict(12, 1, (8, 16, 32, 64), seed=3)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ref_state.keys())        # downs, ups, bottleneck, final_conv
+    for k in sd:
+        assert sd[k].shape == ref_state[k].shape and torch.equal(sd[k], ref_state[k])
+    model = model.to("cuda")
+    X, _ = O.synthetic_batch(3, 12, 1, 16, 16)
+    model.eval()
+    with torch.no_grad():
+        p_eval = model(X.cuda())
+    model.train()
+    p_train = model(X.cuda())
+    assert torch.equal(p_eval, p_train.detach())            # no BatchNorm/Dropout: modes agree bit for bit
+    assert rel(p_eval.cpu(), O.unet_forward(ref_state, X)) < 1e-5
+    # round trip through a checkpoint dict as train.py:522-529 / test.py:134-135 do
+    ckpt = {"model_state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "best_val_loss": 0.1, "epoch": 1}
+    other = ua.UNet(12, 1, (8, 16, 32, 64), compute_dtype="fp32").to("cuda")
+    other.load_state_dict(ckpt["model_state_dict"])
+    with torch.no_grad():
+        assert torch.equal(other(X.cuda()), p_eval)
+    # parameters updated in place by a stock optimiser are picked up (weights are re-packed)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.mul_(0.5)
+        assert not torch.equal(other(X.cuda()), p_eval)
+
+
+def test_errors(ua):
+    cfg = types.SimpleNamespace(model_type="transformer", in_channels=1)
+    with pytest.raises(ValueError, match="Unknown cfg.model_type"):   # models/builders.py:132
+        ua.build_model_from_cfg(cfg)
+    model = ua.UNet(12, 1, (8, 16, 32, 64)).to("cuda")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 12, 16, 16))
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 16, 16, device="cuda"))
+    with pytest.raises(RuntimeError, match="too small"):             # the reference fails the same way (12x12 input)
+        model(torch.zeros(1, 12, 12, 12, device="cuda"))
+    with pytest.raises(RuntimeError, match="double"):
+        ua.UNet(1, 1, (8, 16, 24)).to("cuda")(torch.zeros(1, 1, 16, 16, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_size_properties(ua, dtype):
+    """Size-independent properties at the benchmark's own size (12ch 32x32, batch 512):
+    bitwise run-to-run determinism, linearity of backward in the upstream gradient, and
+    batch additivity (the identity data-parallel training relies on)."""
+    torch.manual_seed(0)
+    model = ua.UNet(12, 1, compute_dtype=dtype).to("cuda")
+    X, Y = O.synthetic_batch(512, 12, 1, 32, 32)
+    X, Y = X.cuda(), Y.cuda()
+    crit = ua.MSELoss()
+
+    def grads(xb, yb, scale=1.0):
+        model.zero_grad(set_to_none=True)
+        loss = crit(model(xb), yb) * scale
+        loss.backward()
+        return loss.detach(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+
+    l1, g1 = grads(X, Y)
+    l2, g2 = grads(X, Y)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    _, g3 = grads(X, Y, scale=4.0)
+    assert rel(g3, 4.0 * g1) < (1e-6 if dtype == "fp32" else 1e-2)
+    _, ga = grads(X[:256], Y[:256])
+    _, gb = grads(X[256:], Y[256:])
+    assert rel(0.5 * (ga + gb), g1) < (2e-5 if dtype == "fp32" else 2e-2)
+    assert torch.isfinite(g1).all()

@@ -1,0 +1,341 @@
+// extern "C" entry points for the single operators (see include/unet_tm_hip.h) and the
+// shared error/dispatch helpers.  Host code only; the kernels live in igemm_*.hip,
+// wgrad_*.hip and pointwise.hip.
+#include "common.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace mi {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return MI_OK;
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e;
+}
+
+int launch_igemm_f32(const IgemmArgs& a, hipStream_t s, const char** name);
+int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
+int launch_wgrad_f32(const WgradArgs& a, hipStream_t s, const char** name);
+int launch_wgrad_bf16(const WgradArgs& a, hipStream_t s, const char** name);
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int launch_igemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** name) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_BF16, "igemm: bad dtype");
+  MI_REQUIRE(a.in && a.w && a.out, "igemm: null pointer");
+  MI_REQUIRE(a.M > 0 && a.M < (1 << 30), "igemm: pixel count out of range");
+  MI_REQUIRE(a.N % 16 == 0 && a.Cin % 16 == 0 && a.Kp % 64 == 0 && a.Kp >= a.taps * a.Cin,
+             "igemm: channel counts must be padded to 16 and K to 64");
+  MI_REQUIRE(a.in_cs % 16 == 0 && a.in_co % 16 == 0 && a.out_cs % 16 == 0 && a.out_co % 16 == 0 &&
+                 a.mask_cs % 16 == 0 && a.mask_co % 16 == 0,
+             "igemm: view strides/offsets must be multiples of 16 elements");
+  MI_REQUIRE(aligned16(a.in) && aligned16(a.w) && aligned16(a.out) && aligned16(a.mask),
+             "igemm: pointers must be 16-byte aligned");
+  MI_REQUIRE(a.epi == E_PLAIN || a.bias != nullptr, "igemm: bias required by this epilogue");
+  MI_REQUIRE(a.epi != E_SHUFFLE_BIAS || (a.shufC % 16 == 0 && a.N == 4 * a.shufC), "igemm: bad shuffle width");
+  MI_REQUIRE(a.in_co + a.Cin <= a.in_cs, "igemm: input channel range exceeds the view stride");
+  return dtype == MI_BF16 ? launch_igemm_bf16(a, s, name) : launch_igemm_f32(a, s, name);
+}
+
+int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split) {
+  const int PB = dtype == MI_BF16 ? 128 : 64;
+  const int64_t tiles = (int64_t)((Na + 63) / 64) * ((K + 63) / 64);
+  int64_t splits = (1024 + tiles - 1) / tiles;
+  const int64_t max_splits = (M + PB - 1) / PB;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int64_t pps = (M + splits - 1) / splits;
+  pps = (pps + PB - 1) / PB * PB;
+  splits = (M + pps - 1) / pps;
+  *pix_per_split = (int)pps;
+  return (int)splits;
+}
+
+int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** name) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_BF16, "wgrad: bad dtype");
+  MI_REQUIRE(a.a && a.b && a.part, "wgrad: null pointer");
+  MI_REQUIRE(a.M > 0 && a.M < (1 << 30), "wgrad: pixel count out of range");
+  MI_REQUIRE(a.Na % 16 == 0 && a.Cb % 16 == 0, "wgrad: channel counts must be padded to 16");
+  MI_REQUIRE(a.a_cs % 16 == 0 && a.a_co % 16 == 0 && a.b_cs % 16 == 0 && a.b_co % 16 == 0,
+             "wgrad: view strides/offsets must be multiples of 16 elements");
+  MI_REQUIRE(aligned16(a.a) && aligned16(a.b), "wgrad: pointers must be 16-byte aligned");
+  MI_REQUIRE(a.splits >= 1 && a.pix_per_split % (dtype == MI_BF16 ? 128 : 64) == 0 &&
+                 (int64_t)a.splits * a.pix_per_split >= a.M,
+             "wgrad: bad pixel split");
+  return dtype == MI_BF16 ? launch_wgrad_bf16(a, s, name) : launch_wgrad_f32(a, s, name);
+}
+
+// Shared argument builders (also used by the whole-network plan).
+IgemmArgs conv3x3_fwd_args(const void* x, int xcs, int xco, const void* wf, const float* bias, void* y, int ycs,
+                           int yco, int B, int H, int W, int Cin, int split, int Cout, int relu) {
+  IgemmArgs a{};
+  a.in = x; a.in_cs = xcs; a.in_co = xco;
+  a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
+  a.Cin = concat_cp(Cin, split);
+  a.taps = 9; a.mode = G_3x3;
+  a.w = wf; a.Kp = (int)kpad(9 * a.Cin);
+  a.N = pad16(Cout);
+  a.bias = bias; a.n_real = Cout;
+  a.out = y; a.out_cs = ycs; a.out_co = yco;
+  a.epi = relu ? E_BIAS_RELU : E_BIAS;
+  a.M = B * H * W;
+  a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
+  return a;
+}
+IgemmArgs conv3x3_dgrad_args(const void* dy, int ycs, int yco, const void* wb, void* dx, int dcs, int dco,
+                             const void* mask, int mcs, int mco, int B, int H, int W, int Cin, int split, int Cout) {
+  IgemmArgs a{};
+  a.in = dy; a.in_cs = ycs; a.in_co = yco;
+  a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
+  a.Cin = pad16(Cout);
+  a.taps = 9; a.mode = G_3x3;
+  a.w = wb; a.Kp = (int)kpad(9 * a.Cin);
+  a.N = concat_cp(Cin, split);
+  a.out = dx; a.out_cs = dcs; a.out_co = dco;
+  a.mask = mask; a.mask_cs = mcs; a.mask_co = mco;
+  a.epi = E_PLAIN;
+  a.M = B * H * W;
+  a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
+  return a;
+}
+IgemmArgs convt_fwd_args(const void* x, int xcs, int xco, const void* wf, const float* bias, void* y, int ycs,
+                         int yco, int B, int H, int W, int Cin, int Cout) {
+  IgemmArgs a{};
+  a.in = x; a.in_cs = xcs; a.in_co = xco;
+  a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
+  a.Cin = pad16(Cin);
+  a.taps = 1; a.mode = G_1x1;
+  a.w = wf; a.Kp = (int)kpad(a.Cin);
+  a.shufC = pad16(Cout);
+  a.N = 4 * a.shufC;
+  a.bias = bias; a.n_real = Cout;
+  a.out = y; a.out_cs = ycs; a.out_co = yco;
+  a.epi = E_SHUFFLE_BIAS;
+  a.M = B * H * W;
+  a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
+  return a;
+}
+IgemmArgs convt_dgrad_args(const void* dy, int ycs, int yco, const void* wb, void* dx, int dcs, int dco,
+                           const void* mask, int mcs, int mco, int B, int H, int W, int Cin, int Cout) {
+  IgemmArgs a{};
+  a.in = dy; a.in_cs = ycs; a.in_co = yco;
+  a.B = B; a.Hi = 2 * H; a.Wi = 2 * W; a.Ho = H; a.Wo = W;
+  a.Cin = pad16(Cout);
+  a.taps = 4; a.mode = G_2x2S2;
+  a.w = wb; a.Kp = (int)kpad(4 * a.Cin);
+  a.N = pad16(Cin);
+  a.out = dx; a.out_cs = dcs; a.out_co = dco;
+  a.mask = mask; a.mask_cs = mcs; a.mask_co = mco;
+  a.epi = E_PLAIN;
+  a.M = B * H * W;
+  a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
+  return a;
+}
+
+struct WgradLayout {
+  int splits, pps;
+  size_t part_bytes, sum_bytes;
+};
+WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
+  WgradLayout l;
+  const int Np = pad16(Cout), K = 9 * concat_cp(Cin, split);
+  l.splits = wgrad_choose_splits(B * H * W, Np, K, dtype, &l.pps);
+  l.part_bytes = (size_t)l.splits * Np * K * sizeof(float);
+  l.sum_bytes = (size_t)l.splits * Np * sizeof(float);
+  return l;
+}
+WgradLayout convt_wgrad_layout(int B, int H, int W, int Cin, int Cout, int dtype) {
+  WgradLayout l;
+  const int Cp = pad16(Cin), K = 4 * pad16(Cout);
+  l.splits = wgrad_choose_splits(B * H * W, Cp, K, dtype, &l.pps);
+  l.part_bytes = (size_t)l.splits * Cp * K * sizeof(float);
+  l.sum_bytes = (size_t)l.splits * K * sizeof(float);
+  return l;
+}
+int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
+                      float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int split,
+                      int Cout, int dtype, hipStream_t s, const char** name) {
+  const WgradLayout l = conv3x3_wgrad_layout(B, H, W, Cin, split, Cout, dtype);
+  if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "conv3x3_wgrad: workspace too small");
+  WgradArgs a{};
+  a.a = dy; a.a_cs = ycs; a.a_co = yco; a.Na = pad16(Cout);
+  a.b = x; a.b_cs = xcs; a.b_co = xco; a.Cb = concat_cp(Cin, split);
+  a.B = B; a.Hb = H; a.Wb = W; a.Ho = H; a.Wo = W;
+  a.taps = 9; a.mode = G_3x3;
+  a.part = (float*)ws;
+  a.rowsum = (float*)((char*)ws + l.part_bytes);
+  a.splits = l.splits; a.pix_per_split = l.pps;
+  a.M = B * H * W;
+  a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
+  int rc = launch_wgrad(a, dtype, s, name);
+  if (rc) return rc;
+  return launch_finalize_conv3(a.part, a.rowsum, l.splits, a.Na, a.Cb, Cout, Cin, split, dW, db, alpha, beta, s);
+}
+int run_convt_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
+                    float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
+                    int dtype, hipStream_t s, const char** name) {
+  const WgradLayout l = convt_wgrad_layout(B, H, W, Cin, Cout, dtype);
+  if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "convt2x2_wgrad: workspace too small");
+  WgradArgs a{};
+  a.a = x; a.a_cs = xcs; a.a_co = xco; a.Na = pad16(Cin);
+  a.b = dy; a.b_cs = ycs; a.b_co = yco; a.Cb = pad16(Cout);
+  a.B = B; a.Hb = 2 * H; a.Wb = 2 * W; a.Ho = H; a.Wo = W;
+  a.taps = 4; a.mode = G_2x2S2;
+  a.part = (float*)ws;
+  a.colsum = (float*)((char*)ws + l.part_bytes);
+  a.splits = l.splits; a.pix_per_split = l.pps;
+  a.M = B * H * W;
+  a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
+  int rc = launch_wgrad(a, dtype, s, name);
+  if (rc) return rc;
+  return launch_finalize_convt(a.part, a.colsum, l.splits, a.Na, a.Cb, Cin, Cout, dW, db, alpha, beta, s);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_version(void) { return 100; }
+const char* mi_last_error(void) { return g_last_error.c_str(); }
+int mi_pad_channels(int c) { return pad16(c); }
+
+int mi_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype, mi_stream s) {
+  MI_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad arguments");
+  MI_REQUIRE(cs % 16 == 0 && co % 16 == 0 && co + pad16(C) <= cs, "nchw_to_nhwc: bad view");
+  return launch_nchw_to_nhwc(src, dst, cs, co, B, C, H, W, dtype, (hipStream_t)s);
+}
+int mi_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W, int dtype, mi_stream s) {
+  MI_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
+  return launch_nhwc_to_nchw(src, cs, co, dst, B, C, H, W, dtype, (hipStream_t)s);
+}
+
+size_t mi_packed_conv3x3_bytes(int Cout, int Cin, int split, int dtype, int which) {
+  const int Np = pad16(Cout), Cp = concat_cp(Cin, split);
+  return (size_t)(which == 0 ? (int64_t)Np * kpad(9 * Cp) : (int64_t)Cp * kpad(9 * Np)) * elem_size(dtype);
+}
+size_t mi_packed_convt2x2_bytes(int Cin, int Cout, int dtype, int which) {
+  const int Np = pad16(Cout), Cp = pad16(Cin);
+  return (size_t)(which == 0 ? (int64_t)4 * Np * kpad(Cp) : (int64_t)Cp * kpad(4 * Np)) * elem_size(dtype);
+}
+int mi_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype, mi_stream s) {
+  MI_REQUIRE(w && Cout > 0 && Cin > 0 && split >= 0 && split < Cin, "pack_conv3x3: bad arguments");
+  return launch_pack_conv3x3(w, wfwd, wbwd, Cout, Cin, split, dtype, (hipStream_t)s);
+}
+int mi_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, mi_stream s) {
+  MI_REQUIRE(w && Cout > 0 && Cin > 0, "pack_convt2x2: bad arguments");
+  return launch_pack_convt2x2(w, wfwd, wbwd, Cin, Cout, dtype, (hipStream_t)s);
+}
+
+int mi_conv3x3_relu_fwd(const void* x, int xcs, int xco, const void* wfwd, const float* bias, void* y, int ycs, int yco,
+                        int B, int H, int W, int Cin, int split, int Cout, int relu, int dtype, mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_fwd: bad shape");
+  return launch_igemm(conv3x3_fwd_args(x, xcs, xco, wfwd, bias, y, ycs, yco, B, H, W, Cin, split, Cout, relu), dtype,
+                      (hipStream_t)s);
+}
+int mi_conv3x3_dgrad(const void* dy, int ycs, int yco, const void* wbwd, void* dx, int dcs, int dco, const void* mask,
+                     int mcs, int mco, int B, int H, int W, int Cin, int split, int Cout, int dtype, mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_dgrad: bad shape");
+  return launch_igemm(conv3x3_dgrad_args(dy, ycs, yco, wbwd, dx, dcs, dco, mask, mcs, mco, B, H, W, Cin, split, Cout),
+                      dtype, (hipStream_t)s);
+}
+size_t mi_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
+  const WgradLayout l = conv3x3_wgrad_layout(B, H, W, Cin, split, Cout, dtype);
+  return l.part_bytes + l.sum_bytes;
+}
+int mi_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
+                     float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int split,
+                     int Cout, int dtype, mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "conv3x3_wgrad: bad arguments");
+  return run_conv3x3_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, split, Cout,
+                           dtype, (hipStream_t)s, nullptr);
+}
+
+int mi_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C, int dtype,
+                    mi_stream s) {
+  MI_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "maxpool2_fwd: bad arguments");
+  return launch_maxpool2_fwd(x, xcs, xco, y, ycs, yco, B, H, W, C, dtype, (hipStream_t)s);
+}
+int mi_maxpool2_bwd(const void* x, int xcs, int xco, const void* dyp, int pcs, int pco, const void* dskip, int scs,
+                    int sco, void* dx, int dcs, int dco, int B, int H, int W, int C, int relu_mask, int dtype,
+                    mi_stream s) {
+  MI_REQUIRE(x && dx && B > 0 && H > 0 && W > 0 && C > 0, "maxpool2_bwd: bad arguments");
+  MI_REQUIRE(dyp || (H / 2) * (W / 2) == 0, "maxpool2_bwd: pooled gradient missing");
+  return launch_maxpool2_bwd(x, xcs, xco, dyp, pcs, pco, dskip, scs, sco, dx, dcs, dco, B, H, W, C, relu_mask, dtype,
+                             (hipStream_t)s);
+}
+
+int mi_convt2x2_fwd(const void* x, int xcs, int xco, const void* wfwd, const float* bias, void* y, int ycs, int yco,
+                    int B, int H, int W, int Cin, int Cout, int dtype, mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "convt2x2_fwd: bad shape");
+  return launch_igemm(convt_fwd_args(x, xcs, xco, wfwd, bias, y, ycs, yco, B, H, W, Cin, Cout), dtype, (hipStream_t)s);
+}
+int mi_convt2x2_dgrad(const void* dy, int ycs, int yco, const void* wbwd, void* dx, int dcs, int dco, const void* mask,
+                      int mcs, int mco, int B, int H, int W, int Cin, int Cout, int dtype, mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "convt2x2_dgrad: bad shape");
+  return launch_igemm(convt_dgrad_args(dy, ycs, yco, wbwd, dx, dcs, dco, mask, mcs, mco, B, H, W, Cin, Cout), dtype,
+                      (hipStream_t)s);
+}
+size_t mi_convt2x2_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int dtype) {
+  const WgradLayout l = convt_wgrad_layout(B, H, W, Cin, Cout, dtype);
+  return l.part_bytes + l.sum_bytes;
+}
+int mi_convt2x2_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
+                      float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
+                      int dtype, mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "convt2x2_wgrad: bad arguments");
+  return run_convt_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, Cout, dtype,
+                         (hipStream_t)s, nullptr);
+}
+
+int mi_conv1x1_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,
+                        int W, int Cin, int Cout, int dtype, mi_stream s) {
+  MI_REQUIRE(x && w && bias && pred && B > 0 && H > 0 && W > 0, "head_fwd: bad arguments");
+  return launch_head_fwd(x, xcs, xco, w, bias, pred, B, H, W, Cin, Cout, dtype, (hipStream_t)s);
+}
+size_t mi_conv1x1_head_ws_bytes(int Cin, int Cout) { return head_ws_bytes(Cin, Cout); }
+int mi_conv1x1_head_bwd(const void* x, int xcs, int xco, const float* w, const float* dpred, void* dx, int dcs, int dco,
+                        float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W,
+                        int Cin, int Cout, int relu_mask, int dtype, mi_stream s) {
+  MI_REQUIRE(x && w && dpred && dx && dW && db && ws && B > 0 && H > 0 && W > 0, "head_bwd: bad arguments");
+  return launch_head_bwd(x, xcs, xco, w, dpred, dx, dcs, dco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, Cout,
+                         relu_mask, dtype, (hipStream_t)s);
+}
+
+size_t mi_mse_ws_bytes(int64_t n) { return mse_ws_bytes(n); }
+int mi_mse_fwd_bwd(const float* pred, const float* target, int64_t n, float* out3, float* dpred, float gscale,
+                   const float* gscale_dev, void* ws, size_t ws_bytes, mi_stream s) {
+  MI_REQUIRE(pred && target && out3 && ws, "mse: null pointer");
+  return launch_mse(pred, target, n, out3, dpred, gscale, gscale_dev, ws, ws_bytes, (hipStream_t)s);
+}
+
+int mi_bilinear_fwd(const void* src, int64_t ssb, int64_t ssc, int64_t ssy, int64_t ssx, int sdt, void* dst,
+                    int64_t dsb, int64_t dsc, int64_t dsy, int64_t dsx, int ddt, int B, int C, int Hin, int Win,
+                    int Hout, int Wout, mi_stream s) {
+  MI_REQUIRE(src && dst && B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "bilinear_fwd: bad arguments");
+  return launch_bilinear_fwd(src, ssb, ssc, ssy, ssx, sdt, dst, dsb, dsc, dsy, dsx, ddt, B, C, Hin, Win, Hout, Wout,
+                             (hipStream_t)s);
+}
+int mi_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy, int64_t osx, int odt, void* din,
+                    int64_t isb, int64_t isc, int64_t isy, int64_t isx, int idt, int B, int C, int Hin, int Win,
+                    int Hout, int Wout, mi_stream s) {
+  MI_REQUIRE(dout && din && B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "bilinear_bwd: bad arguments");
+  return launch_bilinear_bwd(dout, osb, osc, osy, osx, odt, din, isb, isc, isy, isx, idt, B, C, Hin, Win, Hout, Wout,
+                             (hipStream_t)s);
+}
+
+int mi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 int step, float grad_scale, mi_stream s) {
+  MI_REQUIRE(p && g && m && v, "adam: null pointer");
+  return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s);
+}
+
+}  // extern "C"

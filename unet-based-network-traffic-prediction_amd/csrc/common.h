@@ -1,0 +1,133 @@
+// Internal declarations shared by the HIP sources of libunet_tm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "../../include/unet_tm_hip.h"
+
+namespace mi {
+
+constexpr int kPad = 16;  // channel padding granule (elements)
+inline int pad16(int c) { return (c + kPad - 1) / kPad * kPad; }
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+inline int elem_size(int dtype) { return dtype == MI_BF16 ? 2 : 4; }
+
+// Exact unsigned division by a runtime constant for n < 2^31:
+//   q = (uint64(n) * mul) >> shift,  mul = ceil(2^(31+l)/d), l = ceil(log2 d).
+struct FastDiv {
+  uint32_t mul, shift, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = 31 + l;
+  f.mul = (uint32_t)(((1ull << f.shift) + d - 1) / d);
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return (uint32_t)(((uint64_t)n * f.mul) >> f.shift);
+}
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int check_hip(hipError_t e, const char* what);
+
+#define MI_REQUIRE(cond, msg)                                   \
+  do {                                                          \
+    if (!(cond)) return ::mi::fail(MI_EINVAL, std::string(msg)); \
+  } while (0)
+
+// ---------------------------------------------------------------- implicit-GEMM (igemm.hip)
+// out[p][n] = epilogue( sum_{tap,c} in[gather(p,tap)][c] * w[n][tap*Cin + c] )
+enum GatherMode { G_3x3 = 0, G_2x2S2 = 1, G_1x1 = 2 };
+enum Epilogue { E_PLAIN = 0, E_BIAS = 1, E_BIAS_RELU = 2, E_SHUFFLE_BIAS = 3 };
+
+struct IgemmArgs {
+  const void* in; int in_cs, in_co;      // gathered operand (NHWC view)
+  int B, Hi, Wi;                         // its spatial size
+  int Ho, Wo;                            // output pixel grid; M = B*Ho*Wo
+  int Cin;                               // channels per tap (multiple of 16)
+  int taps, mode;
+  const void* w; int Kp;                 // packed weights [N][Kp]
+  int N;                                 // output channels incl. padding (multiple of 16)
+  const float* bias; int n_real;         // bias has n_real entries (unpadded parameter)
+  void* out; int out_cs, out_co;
+  const void* mask; int mask_cs, mask_co;  // optional: out *= (mask > 0)
+  int epi;
+  int shufC;                             // E_SHUFFLE_BIAS: N = 4*shufC
+  int M;
+  FastDiv divHW, divW;                   // by Ho*Wo and by Wo
+};
+int launch_igemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
+
+// ---------------------------------------------------------------- weight gradient (wgrad.hip)
+// part[z][n][k] = sum_{p in split z} a[p][n] * b[gather(p,tap)][c],  k = tap*Cb + c
+// rowsum[z][n]  = sum_p a[p][n]        (if want_rowsum)
+// colsum[z][k]  = sum_p b[gather][k]   (if want_colsum)
+struct WgradArgs {
+  const void* a; int a_cs, a_co; int Na;   // plain operand, Na channels (multiple of 16)
+  const void* b; int b_cs, b_co; int Cb;   // gathered operand, Cb channels per tap
+  int B, Hb, Wb;                           // spatial size of b
+  int Ho, Wo;                              // pixel grid of a; M = B*Ho*Wo
+  int taps, mode;
+  float* part;                             // [splits][Na][K], K = taps*Cb
+  float* rowsum;                           // [splits][Na] or null
+  float* colsum;                           // [splits][K] or null
+  int splits, pix_per_split;
+  int M;
+  FastDiv divHW, divW;
+};
+int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
+int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
+// dW (Cout,Cin,3,3), db from partials laid out [z][Npad][9*Cp] / rowsum [z][Npad]
+int launch_finalize_conv3(const float* part, const float* rowsum, int splits, int Npad, int Cp,
+                          int Cout, int Cin, int split, float* dW, float* db, float alpha, float beta,
+                          hipStream_t s);
+// dW (Cin,Cout,2,2), db from partials [z][Cp_in][4*Npad] / colsum [z][4*Npad]
+int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad,
+                          int Cin, int Cout, float* dW, float* db, float alpha, float beta, hipStream_t s);
+
+// ---------------------------------------------------------------- pointwise (pointwise.hip)
+int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W,
+                        int dtype, hipStream_t s);
+int launch_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W,
+                        int dtype, hipStream_t s);
+int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype,
+                        hipStream_t s);
+int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, hipStream_t s);
+int launch_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W,
+                        int C, int dtype, hipStream_t s);
+int launch_maxpool2_bwd(const void* x, int xcs, int xco, const void* dyp, int pcs, int pco,
+                        const void* dskip, int scs, int sco, void* dx, int dcs, int dco, int B, int H,
+                        int W, int C, int relu_mask, int dtype, hipStream_t s);
+int launch_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred,
+                    int B, int H, int W, int Cin, int Cout, int dtype, hipStream_t s);
+int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float* dpred, void* dx,
+                    int dcs, int dco, float* dW, float* db, float alpha, float beta, void* ws,
+                    size_t ws_bytes, int B, int H, int W, int Cin, int Cout, int relu_mask, int dtype,
+                    hipStream_t s);
+size_t head_ws_bytes(int Cin, int Cout);
+int launch_mse(const float* pred, const float* target, int64_t n, float* out3, float* dpred, float gscale,
+               const float* gscale_dev, void* ws, size_t ws_bytes, hipStream_t s);
+size_t mse_ws_bytes(int64_t n);
+int launch_bilinear_fwd(const void* src, int64_t ssb, int64_t ssc, int64_t ssy, int64_t ssx, int sdt,
+                        void* dst, int64_t dsb, int64_t dsc, int64_t dsy, int64_t dsx, int ddt, int B, int C,
+                        int Hin, int Win, int Hout, int Wout, hipStream_t s);
+int launch_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy, int64_t osx, int odt,
+                        void* din, int64_t isb, int64_t isc, int64_t isy, int64_t isx, int idt, int B, int C,
+                        int Hin, int Win, int Hout, int Wout, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                float eps, int step, float grad_scale, hipStream_t s);
+
+// Packed-weight geometry helpers (elements)
+inline int concat_cp(int Cin, int split) {  // padded input channels incl. concat layout
+  return split > 0 ? pad16(split) + pad16(Cin - split) : pad16(Cin);
+}
+inline int64_t kpad(int64_t k) { return round_up(k, 64); }
+
+}  // namespace mi

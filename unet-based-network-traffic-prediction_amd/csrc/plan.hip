@@ -1,0 +1,699 @@
+// Whole-network launch sequences: the orchestration of UNet.forward
+// (models/unet2d.py:61-102 of the reference) and of its autograd backward, as one host
+// call each.  A plan is immutable shape metadata (workspace layout, flat parameter
+// layout, backward segments); all device memory is the caller's.
+//
+// Workspace tensors and what they correspond to in the reference forward:
+//   x            network input in NHWC                       (forward argument, :61)
+//   a1.l         post-ReLU output of downs[l][0..1]           (:66)
+//   cat.l        decoder input of level l: channels [0,f) = post-ReLU output of
+//                downs[l][2..3] = the skip (:67), [f,2f) = upsampled tensor (:77-84);
+//                torch.cat (:86) therefore never copies
+//   pool.l       self.pool output (:68)
+//   b1, b2       bottleneck activations (:70)
+//   upraw.j      ConvTranspose2d output when it still has to be resized (:81-84)
+//   u1.j, u2.j   post-ReLU outputs of ups[2j+1] (:87)
+//   pred0        final_conv output when a forced out_size resize follows (:92-100)
+// Gradient tensors g.* mirror them; gradients of post-ReLU tensors are stored already
+// multiplied by the ReLU mask (i.e. they are gradients w.r.t. the conv's pre-activation).
+#include "common.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mi {
+
+IgemmArgs conv3x3_fwd_args(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, int, int, int);
+IgemmArgs conv3x3_dgrad_args(const void*, int, int, const void*, void*, int, int, const void*, int, int, int, int, int, int, int, int);
+IgemmArgs convt_fwd_args(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, int);
+IgemmArgs convt_dgrad_args(const void*, int, int, const void*, void*, int, int, const void*, int, int, int, int, int, int, int);
+int run_conv3x3_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
+                      int, int, int, int, int, hipStream_t, const char**);
+int run_convt_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
+                    int, int, int, int, hipStream_t, const char**);
+
+enum LayerKind { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2 };
+struct Layer {
+  std::string prefix;
+  int kind, cin, cout, split;
+  int64_t w_off, b_off;      // element offsets into the flat fp32 parameter buffer
+  size_t wf_off, wb_off;     // byte offsets of the packed operands in the workspace
+};
+struct Tensor {              // an allocation in the workspace
+  std::string name;
+  size_t off, bytes;
+  int B, H, W, C, cs;        // cs = channels incl. padding (NHWC) ; for NCHW fp32 cs = C
+  int layout;                // 0 NHWC plan dtype, 1 fp32 NCHW
+};
+struct Named {               // a view exposed for parity checks
+  std::string name;
+  int tensor, coff, C;
+};
+struct Segment { int64_t lo, hi; };
+struct ProfRec {
+  std::string kernel, label;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+
+}  // namespace mi
+
+using namespace mi;
+
+struct mi_unet_plan {
+  mi_unet_desc d;
+  int L;
+  std::vector<int> h, w;       // spatial size per level (index L = bottleneck)
+  std::vector<bool> direct;    // decoder j writes its transposed conv straight into cat
+  bool out_resize;
+  std::vector<Layer> layers;
+  std::vector<Tensor> tensors;
+  std::vector<Named> named;
+  std::vector<Segment> segs;
+  int64_t flat_elems;
+  size_t ws_bytes, scratch_off, scratch_bytes;
+  bool forward_done;
+  bool profile;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used;
+
+  int tensor_id(const std::string& n) const {
+    for (size_t i = 0; i < tensors.size(); ++i)
+      if (tensors[i].name == n) return (int)i;
+    return -1;
+  }
+  int layer_id(const std::string& p) const {
+    for (size_t i = 0; i < layers.size(); ++i)
+      if (layers[i].prefix == p) return (int)i;
+    return -1;
+  }
+};
+
+namespace {
+
+struct View {
+  void* p;
+  int cs, co;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int add_tensor(mi_unet_plan* P, const std::string& name, int B, int H, int W, int C, int layout, size_t& cursor,
+               int cs_override = 0) {
+  Tensor t;
+  t.name = name; t.B = B; t.H = H; t.W = W; t.C = C; t.layout = layout;
+  t.cs = layout == 0 ? (cs_override ? cs_override : pad16(C)) : C;
+  t.bytes = (size_t)B * H * W * t.cs * (layout == 0 ? elem_size(P->d.dtype) : 4);
+  t.off = cursor;
+  cursor = align_up(cursor + t.bytes, 256);
+  P->tensors.push_back(t);
+  return (int)P->tensors.size() - 1;
+}
+
+struct Run {   // per-call context
+  mi_unet_plan* P;
+  char* ws;
+  const float* params;
+  hipStream_t s;
+  int rc;
+  View view(const std::string& name, int coff = 0) const {
+    const int id = P->tensor_id(name);
+    const Tensor& t = P->tensors[id];
+    return View{ws + t.off, t.cs, coff};
+  }
+  const float* W(const Layer& l) const { return params + l.w_off; }
+  const float* Bv(const Layer& l) const { return params + l.b_off; }
+};
+
+struct Scope {   // brackets one launch with events when profiling is on
+  mi_unet_plan* P;
+  hipStream_t s;
+  int idx;
+  Scope(mi_unet_plan* p, hipStream_t st, const char* label, double flops, double bytes) : P(p), s(st), idx(-1) {
+    if (!P->profile) return;
+    while (P->event_pool.size() < P->events_used + 2) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      P->event_pool.push_back(e);
+    }
+    ProfRec r;
+    r.kernel = "?"; r.label = label; r.flops = flops; r.bytes = bytes;
+    r.e0 = P->event_pool[P->events_used++];
+    r.e1 = P->event_pool[P->events_used++];
+    hipEventRecord(r.e0, s);
+    P->prof.push_back(r);
+    idx = (int)P->prof.size() - 1;
+  }
+  void kernel(const char* k) { if (idx >= 0 && k) P->prof[idx].kernel = k; }
+  ~Scope() { if (idx >= 0) hipEventRecord(P->prof[idx].e1, s); }
+};
+
+double esz(const mi_unet_plan* P) { return (double)elem_size(P->d.dtype); }
+
+#define RUN(expr)                 \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != MI_OK) return rc__; \
+  } while (0)
+
+int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, const char* label) {
+  const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
+  const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
+  Scope sc(r.P, r.s, label, fl, by);
+  const char* k = nullptr;
+  IgemmArgs a = conv3x3_fwd_args(x.p, x.cs, x.co, r.ws + l.wf_off, r.Bv(l), y.p, y.cs, y.co, B, H, W, l.cin, l.split,
+                                 l.cout, 1);
+  int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
+  sc.kernel(k);
+  return rc;
+}
+int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, int B, int H, int W, const char* label) {
+  const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
+  const double by = (double)B * H * W * (l.cin * (mask ? 2 : 1) + l.cout) * esz(r.P);
+  Scope sc(r.P, r.s, label, fl, by);
+  const char* k = nullptr;
+  IgemmArgs a = conv3x3_dgrad_args(dy.p, dy.cs, dy.co, r.ws + l.wb_off, dx.p, dx.cs, dx.co, mask ? mask->p : nullptr,
+                                   mask ? mask->cs : 0, mask ? mask->co : 0, B, H, W, l.cin, l.split, l.cout);
+  int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
+  sc.kernel(k);
+  return rc;
+}
+int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float alpha, float beta, int B, int H, int W,
+                  const char* label) {
+  const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
+  const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P) + 4.0 * l.cout * l.cin * 9;
+  Scope sc(r.P, r.s, label, fl, by);
+  const char* k = nullptr;
+  int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
+                             r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout, r.P->d.dtype,
+                             r.s, &k);
+  sc.kernel(k);
+  return rc;
+}
+
+void bil_strides_nhwc(const Tensor& t, int64_t s[4]) {
+  s[0] = (int64_t)t.H * t.W * t.cs; s[1] = 1; s[2] = (int64_t)t.W * t.cs; s[3] = t.cs;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
+  MI_REQUIRE(desc && out, "plan_create: null pointer");
+  const mi_unet_desc& d = *desc;
+  MI_REQUIRE(d.n_levels >= 1 && d.n_levels <= 8, "plan_create: n_levels must be 1..8");
+  MI_REQUIRE(d.in_channels > 0 && d.out_channels > 0 && d.batch > 0 && d.height > 0 && d.width > 0,
+             "plan_create: bad shape");
+  MI_REQUIRE(d.dtype == MI_F32 || d.dtype == MI_BF16, "plan_create: bad dtype");
+  MI_REQUIRE(d.out_channels <= 16 && pad16(d.features[0]) <= 64, "plan_create: head supports features[0] <= 64, out_channels <= 16");
+  for (int i = 0; i < d.n_levels; ++i) {
+    MI_REQUIRE(d.features[i] > 0, "plan_create: features must be positive");
+    // The reference only runs when widths double (ConvTranspose2d(2f, f) consumes the
+    // previous block's output, models/unet2d.py:45-48).
+    if (i > 0) MI_REQUIRE(d.features[i] == 2 * d.features[i - 1], "plan_create: features must double per level");
+  }
+  {
+    int hh = d.height, ww = d.width;
+    for (int i = 0; i < d.n_levels; ++i) { hh /= 2; ww /= 2; }
+    // the same failure the reference raises from max_pool2d ("Output size is too small")
+    MI_REQUIRE(hh >= 1 && ww >= 1, "plan_create: input too small for this many 2x2 pools");
+  }
+  mi_unet_plan* P = new mi_unet_plan();
+  P->d = d;
+  const int L = P->L = d.n_levels;
+  const int B = d.batch;
+  P->forward_done = false;
+  P->profile = false;
+  P->events_used = 0;
+  P->h.resize(L + 1); P->w.resize(L + 1);
+  P->h[0] = d.height; P->w[0] = d.width;
+  for (int l = 0; l < L; ++l) { P->h[l + 1] = P->h[l] / 2; P->w[l + 1] = P->w[l] / 2; }
+
+  // ---- layers in construction order (models/unet2d.py:24-59)
+  auto add_layer = [&](const std::string& p, int kind, int cin, int cout, int split) {
+    Layer l; l.prefix = p; l.kind = kind; l.cin = cin; l.cout = cout; l.split = split;
+    l.w_off = l.b_off = 0; l.wf_off = l.wb_off = 0;
+    P->layers.push_back(l);
+  };
+  int ch = d.in_channels;
+  for (int l = 0; l < L; ++l) {
+    add_layer("downs." + std::to_string(l) + ".0", K_CONV3, ch, d.features[l], 0);
+    add_layer("downs." + std::to_string(l) + ".2", K_CONV3, d.features[l], d.features[l], 0);
+    ch = d.features[l];
+  }
+  const int fb = d.features[L - 1];
+  add_layer("bottleneck.0", K_CONV3, fb, 2 * fb, 0);
+  add_layer("bottleneck.2", K_CONV3, 2 * fb, 2 * fb, 0);
+  for (int j = 0; j < L; ++j) {
+    const int f = d.features[L - 1 - j];
+    add_layer("ups." + std::to_string(2 * j), K_CONVT, 2 * f, f, 0);
+    add_layer("ups." + std::to_string(2 * j + 1) + ".0", K_CONV3, 2 * f, f, f);
+    add_layer("ups." + std::to_string(2 * j + 1) + ".2", K_CONV3, f, f, 0);
+  }
+  add_layer("final_conv", K_CONV1, d.features[0], d.out_channels, 0);
+  int64_t off = 0;
+  for (auto& l : P->layers) {
+    const int64_t nw = l.kind == K_CONV3 ? (int64_t)l.cout * l.cin * 9
+                     : l.kind == K_CONVT ? (int64_t)l.cin * l.cout * 4 : (int64_t)l.cout * l.cin;
+    l.w_off = off; off = round_up(off + nw, 64);
+    l.b_off = off; off = round_up(off + l.cout, 64);
+  }
+  P->flat_elems = off;
+
+  // ---- backward segments (execution order; flat ranges descend)
+  auto seg_of = [&](int first, int last) {
+    Segment s; s.lo = P->layers[first].w_off;
+    s.hi = last + 1 < (int)P->layers.size() ? P->layers[last + 1].w_off : P->flat_elems;
+    return s;
+  };
+  const int n_layers = (int)P->layers.size();
+  P->segs.push_back(seg_of(n_layers - 1, n_layers - 1));                   // head
+  for (int j = L - 1; j >= 0; --j) {                                       // decoder blocks, last first
+    const int first = P->layer_id("ups." + std::to_string(2 * j));
+    P->segs.push_back(seg_of(first, first + 2));
+  }
+  { const int first = P->layer_id("bottleneck.0"); P->segs.push_back(seg_of(first, first + 1)); }
+  for (int l = L - 1; l >= 0; --l) {
+    const int first = P->layer_id("downs." + std::to_string(l) + ".0");
+    P->segs.push_back(seg_of(first, first + 1));
+  }
+
+  // ---- workspace tensors
+  size_t cur = 0;
+  const bool train = true;  // gradient tensors are laid out after the forward ones; an inference-only
+                            // caller simply passes mi_unet_plan_workspace_bytes(plan) minus nothing: see fwd_bytes
+  (void)train;
+  add_tensor(P, "x", B, d.height, d.width, d.in_channels, 0, cur);
+  for (int l = 0; l < L; ++l) {
+    const int f = d.features[l];
+    add_tensor(P, "a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
+    add_tensor(P, "cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad16(f));
+    add_tensor(P, "pool." + std::to_string(l), B, P->h[l + 1], P->w[l + 1], f, 0, cur);
+  }
+  add_tensor(P, "b1", B, P->h[L], P->w[L], 2 * fb, 0, cur);
+  add_tensor(P, "b2", B, P->h[L], P->w[L], 2 * fb, 0, cur);
+  P->direct.resize(L);
+  for (int j = 0; j < L; ++j) {
+    const int l = L - 1 - j, f = d.features[l];
+    const int hin = P->h[l + 1], win = P->w[l + 1];
+    P->direct[j] = (2 * hin == P->h[l] && 2 * win == P->w[l]);
+    if (!P->direct[j]) add_tensor(P, "upraw." + std::to_string(j), B, 2 * hin, 2 * win, f, 0, cur);
+    add_tensor(P, "u1." + std::to_string(j), B, P->h[l], P->w[l], f, 0, cur);
+    add_tensor(P, "u2." + std::to_string(j), B, P->h[l], P->w[l], f, 0, cur);
+  }
+  P->out_resize = d.out_h > 0 && d.out_w > 0 && (d.out_h != d.height || d.out_w != d.width);
+  if (P->out_resize) add_tensor(P, "pred0", B, d.height, d.width, d.out_channels, 1, cur);
+  // packed weights
+  for (auto& l : P->layers) {
+    if (l.kind == K_CONV3) {
+      l.wf_off = cur; cur = align_up(cur + mi_packed_conv3x3_bytes(l.cout, l.cin, l.split, d.dtype, 0), 256);
+      l.wb_off = cur; cur = align_up(cur + mi_packed_conv3x3_bytes(l.cout, l.cin, l.split, d.dtype, 1), 256);
+    } else if (l.kind == K_CONVT) {
+      l.wf_off = cur; cur = align_up(cur + mi_packed_convt2x2_bytes(l.cin, l.cout, d.dtype, 0), 256);
+      l.wb_off = cur; cur = align_up(cur + mi_packed_convt2x2_bytes(l.cin, l.cout, d.dtype, 1), 256);
+    }
+  }
+  // gradient tensors
+  if (d.need_input_grad) add_tensor(P, "g.x", B, d.height, d.width, d.in_channels, 0, cur);
+  for (int l = 0; l < L; ++l) {
+    const int f = d.features[l];
+    add_tensor(P, "g.a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
+    add_tensor(P, "g.cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad16(f));
+    add_tensor(P, "g.pool." + std::to_string(l), B, P->h[l + 1], P->w[l + 1], f, 0, cur);
+  }
+  add_tensor(P, "g.b1", B, P->h[L], P->w[L], 2 * fb, 0, cur);
+  add_tensor(P, "g.b2", B, P->h[L], P->w[L], 2 * fb, 0, cur);
+  for (int j = 0; j < L; ++j) {
+    const int l = L - 1 - j, f = d.features[l];
+    if (!P->direct[j]) add_tensor(P, "g.upraw." + std::to_string(j), B, 2 * P->h[l + 1], 2 * P->w[l + 1], f, 0, cur);
+    add_tensor(P, "g.u1." + std::to_string(j), B, P->h[l], P->w[l], f, 0, cur);
+    add_tensor(P, "g.u2." + std::to_string(j), B, P->h[l], P->w[l], f, 0, cur);
+  }
+  if (P->out_resize) add_tensor(P, "g.pred0", B, d.height, d.width, d.out_channels, 1, cur);
+  // scratch for weight-gradient partials (layers run one after another on one stream)
+  size_t scratch = head_ws_bytes(d.features[0], d.out_channels);
+  {
+    int lvl_h, lvl_w;
+    for (const auto& l : P->layers) {
+      // spatial size of the layer's OUTPUT grid for conv3 / INPUT grid for convT
+      if (l.prefix.rfind("downs.", 0) == 0) { const int i = std::stoi(l.prefix.substr(6)); lvl_h = P->h[i]; lvl_w = P->w[i]; }
+      else if (l.prefix.rfind("bottleneck.", 0) == 0) { lvl_h = P->h[L]; lvl_w = P->w[L]; }
+      else if (l.prefix.rfind("ups.", 0) == 0) {
+        const int idx = std::stoi(l.prefix.substr(4)); const int lv = L - 1 - idx / 2;
+        if (l.kind == K_CONVT) { lvl_h = P->h[lv + 1]; lvl_w = P->w[lv + 1]; } else { lvl_h = P->h[lv]; lvl_w = P->w[lv]; }
+      } else continue;
+      const size_t need = l.kind == K_CONV3 ? mi_conv3x3_wgrad_ws_bytes(B, lvl_h, lvl_w, l.cin, l.split, l.cout, d.dtype)
+                                            : mi_convt2x2_wgrad_ws_bytes(B, lvl_h, lvl_w, l.cin, l.cout, d.dtype);
+      if (need > scratch) scratch = need;
+    }
+  }
+  P->scratch_off = cur; P->scratch_bytes = align_up(scratch, 256);
+  cur += P->scratch_bytes;
+  P->ws_bytes = cur;
+
+  // ---- named views for parity checks (names follow the reference's module paths)
+  auto name_view = [&](const std::string& n, const std::string& tensor, int coff, int C) {
+    const int id = P->tensor_id(tensor);
+    if (id >= 0) P->named.push_back(Named{n, id, coff, C});
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::string a = pass ? "grad." : "act.", t = pass ? "g." : "";
+    if (pass == 0) name_view("act.x", "x", 0, d.in_channels); else name_view("grad.x", "g.x", 0, d.in_channels);
+    for (int l = 0; l < L; ++l) {
+      const int f = d.features[l]; const std::string s = std::to_string(l);
+      name_view(a + "downs." + s + ".1", t + "a1." + s, 0, f);
+      name_view(a + "downs." + s + ".3", t + "cat." + s, 0, f);
+      name_view(a + "pool." + s, t + "pool." + s, 0, f);
+    }
+    name_view(a + "bottleneck.1", t + "b1", 0, 2 * fb);
+    name_view(a + "bottleneck.3", t + "b2", 0, 2 * fb);
+    for (int j = 0; j < L; ++j) {
+      const int l = L - 1 - j, f = d.features[l]; const std::string s = std::to_string(j), sl = std::to_string(l);
+      if (P->direct[j]) {
+        name_view(a + "ups." + std::to_string(2 * j), t + "cat." + sl, pad16(f), f);
+      } else {
+        name_view(a + "ups." + std::to_string(2 * j), t + "upraw." + s, 0, f);
+        name_view(a + "align." + s, t + "cat." + sl, pad16(f), f);
+      }
+      name_view(a + "ups." + std::to_string(2 * j + 1) + ".1", t + "u1." + s, 0, f);
+      name_view(a + "ups." + std::to_string(2 * j + 1) + ".3", t + "u2." + s, 0, f);
+    }
+    if (P->out_resize) name_view(a + "final_conv", t + "pred0", 0, d.out_channels);
+  }
+  *out = P;
+  return MI_OK;
+}
+
+void mi_unet_plan_destroy(mi_unet_plan* plan) {
+  if (!plan) return;
+  for (hipEvent_t e : plan->event_pool) hipEventDestroy(e);
+  delete plan;
+}
+size_t mi_unet_plan_workspace_bytes(const mi_unet_plan* plan) { return plan ? plan->ws_bytes : 0; }
+int64_t mi_unet_plan_flat_elems(const mi_unet_plan* plan) { return plan ? plan->flat_elems : 0; }
+int mi_unet_plan_num_params(const mi_unet_plan* plan) { return plan ? 2 * (int)plan->layers.size() : 0; }
+int mi_unet_plan_param_info(const mi_unet_plan* plan, int i, char* name, int name_cap, int64_t* flat_offset,
+                            int64_t shape[4], int* ndim) {
+  MI_REQUIRE(plan && i >= 0 && i < 2 * (int)plan->layers.size(), "param_info: index out of range");
+  const Layer& l = plan->layers[i / 2];
+  const bool is_w = (i % 2) == 0;
+  const std::string n = l.prefix + (is_w ? ".weight" : ".bias");
+  if (name && name_cap > 0) { strncpy(name, n.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (flat_offset) *flat_offset = is_w ? l.w_off : l.b_off;
+  if (shape && ndim) {
+    if (!is_w) { shape[0] = l.cout; *ndim = 1; }
+    else if (l.kind == K_CONV3) { shape[0] = l.cout; shape[1] = l.cin; shape[2] = shape[3] = 3; *ndim = 4; }
+    else if (l.kind == K_CONVT) { shape[0] = l.cin; shape[1] = l.cout; shape[2] = shape[3] = 2; *ndim = 4; }
+    else { shape[0] = l.cout; shape[1] = l.cin; shape[2] = shape[3] = 1; *ndim = 4; }
+  }
+  return MI_OK;
+}
+int mi_unet_plan_num_tensors(const mi_unet_plan* plan) { return plan ? (int)plan->named.size() : 0; }
+int mi_unet_plan_tensor_info(const mi_unet_plan* plan, int i, char* name, int name_cap, int64_t* ws_offset_bytes,
+                             int dims[4], int* cstride, int* coff, int* layout) {
+  MI_REQUIRE(plan && i >= 0 && i < (int)plan->named.size(), "tensor_info: index out of range");
+  const Named& v = plan->named[i];
+  const Tensor& t = plan->tensors[v.tensor];
+  if (name && name_cap > 0) { strncpy(name, v.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (ws_offset_bytes) *ws_offset_bytes = (int64_t)t.off;
+  if (dims) { dims[0] = t.B; dims[1] = t.H; dims[2] = t.W; dims[3] = v.C; }
+  if (cstride) *cstride = t.cs;
+  if (coff) *coff = v.coff;
+  if (layout) *layout = t.layout;
+  return MI_OK;
+}
+int mi_unet_plan_num_segments(const mi_unet_plan* plan) { return plan ? (int)plan->segs.size() : 0; }
+int mi_unet_plan_segment_range(const mi_unet_plan* plan, int seg, int64_t* lo, int64_t* hi) {
+  MI_REQUIRE(plan && seg >= 0 && seg < (int)plan->segs.size(), "segment_range: index out of range");
+  if (lo) *lo = plan->segs[seg].lo;
+  if (hi) *hi = plan->segs[seg].hi;
+  return MI_OK;
+}
+
+int mi_unet_profile_enable(mi_unet_plan* plan, int on) {
+  MI_REQUIRE(plan, "profile_enable: null plan");
+  plan->profile = on != 0;
+  plan->prof.clear();
+  plan->events_used = 0;
+  return MI_OK;
+}
+int mi_unet_profile_count(const mi_unet_plan* plan) { return plan ? (int)plan->prof.size() : 0; }
+int mi_unet_profile_read(mi_unet_plan* plan, int i, char* kernel, int kcap, char* label, int lcap, double* flops,
+                         double* bytes, float* ms) {
+  MI_REQUIRE(plan && i >= 0 && i < (int)plan->prof.size(), "profile_read: index out of range");
+  ProfRec& r = plan->prof[i];
+  if (kernel && kcap > 0) { strncpy(kernel, r.kernel.c_str(), kcap - 1); kernel[kcap - 1] = 0; }
+  if (label && lcap > 0) { strncpy(label, r.label.c_str(), lcap - 1); label[lcap - 1] = 0; }
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  if (ms) {
+    int rc = check_hip(hipEventSynchronize(r.e1), "profile_read: event sync");
+    if (rc) return rc;
+    rc = check_hip(hipEventElapsedTime(ms, r.e0, r.e1), "profile_read: elapsed");
+    if (rc) return rc;
+  }
+  return MI_OK;
+}
+
+int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_flat, void* ws, size_t ws_bytes,
+                    float* pred_nchw, int flags, mi_stream stream) {
+  MI_REQUIRE(P && x_nchw && params_flat && ws && pred_nchw, "unet_forward: null pointer");
+  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_forward: workspace too small");
+  MI_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)params_flat & 15) == 0, "unet_forward: workspace must be 256-byte aligned");
+  const mi_unet_desc& d = P->d;
+  const int L = P->L, B = d.batch, dt = d.dtype;
+  Run r{P, (char*)ws, params_flat, (hipStream_t)stream, 0};
+  if (P->profile) { P->prof.clear(); P->events_used = 0; }
+
+  if (flags & MI_FWD_REPACK) {
+    const bool train = (flags & MI_FWD_TRAIN) != 0;
+    Scope sc(P, r.s, "pack_weights", 0, 0);
+    sc.kernel("pack");
+    for (const auto& l : P->layers) {
+      if (l.kind == K_CONV3)
+        RUN(launch_pack_conv3x3(r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.cout, l.cin, l.split, dt, r.s));
+      else if (l.kind == K_CONVT)
+        RUN(launch_pack_convt2x2(r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.cin, l.cout, dt, r.s));
+    }
+  }
+  {
+    Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
+    sc.kernel("nchw_to_nhwc");
+    View x = r.view("x");
+    RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
+  }
+  View cur = r.view("x");
+  for (int l = 0; l < L; ++l) {
+    const std::string s = std::to_string(l);
+    const int f = d.features[l];
+    const Layer& c1 = P->layers[P->layer_id("downs." + s + ".0")];
+    const Layer& c2 = P->layers[P->layer_id("downs." + s + ".2")];
+    View a1 = r.view("a1." + s), cat = r.view("cat." + s), pool = r.view("pool." + s);
+    RUN(do_conv_fwd(r, c1, cur, a1, B, P->h[l], P->w[l], c1.prefix.c_str()));
+    RUN(do_conv_fwd(r, c2, a1, cat, B, P->h[l], P->w[l], c2.prefix.c_str()));
+    {
+      Scope sc(P, r.s, ("pool." + s).c_str(), 0, (double)B * P->h[l] * P->w[l] * f * 1.25 * esz(P));
+      sc.kernel("maxpool2_fwd");
+      RUN(launch_maxpool2_fwd(cat.p, cat.cs, 0, pool.p, pool.cs, 0, B, P->h[l], P->w[l], f, dt, r.s));
+    }
+    cur = pool;
+  }
+  {
+    const Layer& c1 = P->layers[P->layer_id("bottleneck.0")];
+    const Layer& c2 = P->layers[P->layer_id("bottleneck.2")];
+    View b1 = r.view("b1"), b2 = r.view("b2");
+    RUN(do_conv_fwd(r, c1, cur, b1, B, P->h[L], P->w[L], c1.prefix.c_str()));
+    RUN(do_conv_fwd(r, c2, b1, b2, B, P->h[L], P->w[L], c2.prefix.c_str()));
+    cur = b2;
+  }
+  for (int j = 0; j < L; ++j) {
+    const int l = L - 1 - j, f = d.features[l], fp = pad16(f);
+    const std::string s = std::to_string(j), sl = std::to_string(l);
+    const Layer& up = P->layers[P->layer_id("ups." + std::to_string(2 * j))];
+    const Layer& c1 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".0")];
+    const Layer& c2 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".2")];
+    const int hin = P->h[l + 1], win = P->w[l + 1];
+    View cat = r.view("cat." + sl);
+    View dst = P->direct[j] ? View{cat.p, cat.cs, fp} : r.view("upraw." + s);
+    {
+      const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
+      Scope sc(P, r.s, up.prefix.c_str(), fl, (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P));
+      const char* k = nullptr;
+      IgemmArgs a = convt_fwd_args(cur.p, cur.cs, cur.co, r.ws + up.wf_off, r.Bv(up), dst.p, dst.cs, dst.co, B, hin, win,
+                                   up.cin, up.cout);
+      int rc = launch_igemm(a, dt, r.s, &k);
+      sc.kernel(k);
+      RUN(rc);
+    }
+    if (!P->direct[j]) {
+      const Tensor& tu = P->tensors[P->tensor_id("upraw." + s)];
+      const Tensor& tc = P->tensors[P->tensor_id("cat." + sl)];
+      int64_t ss[4], ds[4];
+      bil_strides_nhwc(tu, ss); bil_strides_nhwc(tc, ds);
+      Scope sc(P, r.s, ("align." + s).c_str(), 0, (double)B * f * esz(P) * (4.0 * hin * win + P->h[l] * P->w[l]));
+      sc.kernel("bilinear_fwd");
+      char* dptr = (char*)cat.p + (size_t)fp * elem_size(dt);
+      RUN(launch_bilinear_fwd(dst.p, ss[0], ss[1], ss[2], ss[3], dt, dptr, ds[0], ds[1], ds[2], ds[3], dt, B, fp,
+                              2 * hin, 2 * win, P->h[l], P->w[l], r.s));
+    }
+    View u1 = r.view("u1." + s), u2 = r.view("u2." + s);
+    RUN(do_conv_fwd(r, c1, cat, u1, B, P->h[l], P->w[l], c1.prefix.c_str()));
+    RUN(do_conv_fwd(r, c2, u1, u2, B, P->h[l], P->w[l], c2.prefix.c_str()));
+    cur = u2;
+  }
+  {
+    const Layer& hd = P->layers.back();
+    float* pred0 = P->out_resize ? (float*)(r.ws + P->tensors[P->tensor_id("pred0")].off) : pred_nchw;
+    {
+      Scope sc(P, r.s, "final_conv", 2.0 * B * d.height * d.width * (double)hd.cin * hd.cout,
+               (double)B * d.height * d.width * (hd.cin * esz(P) + 4.0 * hd.cout));
+      sc.kernel("head_fwd");
+      RUN(launch_head_fwd(cur.p, cur.cs, cur.co, r.W(hd), r.Bv(hd), pred0, B, d.height, d.width, hd.cin, hd.cout, dt, r.s));
+    }
+    if (P->out_resize) {
+      const int C = d.out_channels, H = d.height, W = d.width;
+      Scope sc(P, r.s, "out_resize", 0, 4.0 * B * C * ((double)H * W + (double)d.out_h * d.out_w));
+      sc.kernel("bilinear_fwd");
+      RUN(launch_bilinear_fwd(pred0, (int64_t)C * H * W, (int64_t)H * W, W, 1, MI_F32, pred_nchw,
+                              (int64_t)C * d.out_h * d.out_w, (int64_t)d.out_h * d.out_w, d.out_w, 1, MI_F32, B, C, H, W,
+                              d.out_h, d.out_w, r.s));
+    }
+  }
+  P->forward_done = true;
+  return MI_OK;
+}
+
+int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* params_flat, void* ws, size_t ws_bytes,
+                     float* grads, float alpha, float beta, int seg_lo, int seg_hi, float* dx_nchw, mi_stream stream) {
+  MI_REQUIRE(P && dpred_nchw && params_flat && ws && grads, "unet_backward: null pointer");
+  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_backward: workspace too small");
+  if (!P->forward_done) return fail(MI_ESTATE, "unet_backward: no forward pass has been run on this plan");
+  const int nseg = (int)P->segs.size();
+  MI_REQUIRE(seg_lo >= 0 && seg_hi <= nseg && seg_lo <= seg_hi, "unet_backward: bad segment range");
+  MI_REQUIRE(!P->d.need_input_grad || dx_nchw || seg_hi < nseg, "unet_backward: dx buffer required");
+  const mi_unet_desc& d = P->d;
+  const int L = P->L, B = d.batch, dt = d.dtype;
+  Run r{P, (char*)ws, params_flat, (hipStream_t)stream, 0};
+
+  for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    if (seg == 0) {
+      // ---- head (and the forced output resize in front of it)
+      const Layer& hd = P->layers.back();
+      const float* dp0 = dpred_nchw;
+      if (P->out_resize) {
+        float* g0 = (float*)(r.ws + P->tensors[P->tensor_id("g.pred0")].off);
+        const int C = d.out_channels, H = d.height, W = d.width;
+        Scope sc(P, r.s, "out_resize.bwd", 0, 4.0 * B * C * ((double)H * W + (double)d.out_h * d.out_w));
+        sc.kernel("bilinear_bwd");
+        RUN(launch_bilinear_bwd(dpred_nchw, (int64_t)C * d.out_h * d.out_w, (int64_t)d.out_h * d.out_w, d.out_w, 1,
+                                MI_F32, g0, (int64_t)C * H * W, (int64_t)H * W, W, 1, MI_F32, B, C, H, W, d.out_h,
+                                d.out_w, r.s));
+        dp0 = g0;
+      }
+      const std::string s = std::to_string(L - 1);
+      View u2 = r.view("u2." + s), gu2 = r.view("g.u2." + s);
+      Scope sc(P, r.s, "final_conv.bwd", 4.0 * B * d.height * d.width * (double)hd.cin * hd.cout,
+               (double)B * d.height * d.width * (2.0 * hd.cin * esz(P) + 4.0 * hd.cout));
+      sc.kernel("head_bwd");
+      RUN(launch_head_bwd(u2.p, u2.cs, 0, r.W(hd), dp0, gu2.p, gu2.cs, 0, grads + hd.w_off, grads + hd.b_off, alpha, beta,
+                          r.ws + P->scratch_off, P->scratch_bytes, B, d.height, d.width, hd.cin, hd.cout, 1, dt, r.s));
+    } else if (seg <= L) {
+      // ---- decoder block j (levels from the output side inwards)
+      const int j = L - seg, l = L - 1 - j, f = d.features[l], fp = pad16(f);
+      const std::string s = std::to_string(j), sl = std::to_string(l);
+      const Layer& up = P->layers[P->layer_id("ups." + std::to_string(2 * j))];
+      const Layer& c1 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".0")];
+      const Layer& c2 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".2")];
+      const int H = P->h[l], W = P->w[l], hin = P->h[l + 1], win = P->w[l + 1];
+      View u1 = r.view("u1." + s), gu1 = r.view("g.u1." + s), gu2 = r.view("g.u2." + s);
+      View cat = r.view("cat." + sl), gcat = r.view("g.cat." + sl);
+      RUN(do_conv_wgrad(r, c2, u1, gu2, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
+      RUN(do_conv_dgrad(r, c2, gu2, gu1, &u1, B, H, W, (c2.prefix + ".dgrad").c_str()));
+      RUN(do_conv_wgrad(r, c1, cat, gu1, grads, alpha, beta, B, H, W, (c1.prefix + ".wgrad").c_str()));
+      RUN(do_conv_dgrad(r, c1, gu1, gcat, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
+      View dyT{gcat.p, gcat.cs, fp};
+      if (!P->direct[j]) {
+        View gup = r.view("g.upraw." + s);
+        const Tensor& tu = P->tensors[P->tensor_id("g.upraw." + s)];
+        const Tensor& tc = P->tensors[P->tensor_id("g.cat." + sl)];
+        int64_t us[4], cs[4];
+        bil_strides_nhwc(tu, us); bil_strides_nhwc(tc, cs);
+        Scope sc(P, r.s, ("align." + s + ".bwd").c_str(), 0, (double)B * f * esz(P) * (4.0 * hin * win + (double)H * W));
+        sc.kernel("bilinear_bwd");
+        const char* src = (const char*)gcat.p + (size_t)fp * elem_size(dt);
+        RUN(launch_bilinear_bwd(src, cs[0], cs[1], cs[2], cs[3], dt, gup.p, us[0], us[1], us[2], us[3], dt, B, fp,
+                                2 * hin, 2 * win, H, W, r.s));
+        dyT = gup;
+      }
+      View prev = j == 0 ? r.view("b2") : r.view("u2." + std::to_string(j - 1));
+      View gprev = j == 0 ? r.view("g.b2") : r.view("g.u2." + std::to_string(j - 1));
+      {
+        const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
+        Scope sc(P, r.s, (up.prefix + ".wgrad").c_str(), fl, (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P));
+        const char* k = nullptr;
+        int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
+                                 alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
+                                 r.s, &k);
+        sc.kernel(k);
+        RUN(rc);
+      }
+      {
+        const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
+        Scope sc(P, r.s, (up.prefix + ".dgrad").c_str(), fl, (double)B * hin * win * (2.0 * up.cin + 4.0 * up.cout) * esz(P));
+        const char* k = nullptr;
+        IgemmArgs a = convt_dgrad_args(dyT.p, dyT.cs, dyT.co, r.ws + up.wb_off, gprev.p, gprev.cs, gprev.co, prev.p,
+                                       prev.cs, prev.co, B, hin, win, up.cin, up.cout);
+        int rc = launch_igemm(a, dt, r.s, &k);
+        sc.kernel(k);
+        RUN(rc);
+      }
+    } else if (seg == L + 1) {
+      // ---- bottleneck
+      const Layer& c1 = P->layers[P->layer_id("bottleneck.0")];
+      const Layer& c2 = P->layers[P->layer_id("bottleneck.2")];
+      const int H = P->h[L], W = P->w[L];
+      View b1 = r.view("b1"), gb1 = r.view("g.b1"), gb2 = r.view("g.b2");
+      View pin = r.view("pool." + std::to_string(L - 1)), gpin = r.view("g.pool." + std::to_string(L - 1));
+      RUN(do_conv_wgrad(r, c2, b1, gb2, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
+      RUN(do_conv_dgrad(r, c2, gb2, gb1, &b1, B, H, W, (c2.prefix + ".dgrad").c_str()));
+      RUN(do_conv_wgrad(r, c1, pin, gb1, grads, alpha, beta, B, H, W, (c1.prefix + ".wgrad").c_str()));
+      RUN(do_conv_dgrad(r, c1, gb1, gpin, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
+    } else {
+      // ---- encoder level l
+      const int l = L - 1 - (seg - (L + 2)), f = d.features[l];
+      const std::string s = std::to_string(l);
+      const Layer& c1 = P->layers[P->layer_id("downs." + s + ".0")];
+      const Layer& c2 = P->layers[P->layer_id("downs." + s + ".2")];
+      const int H = P->h[l], W = P->w[l];
+      View a1 = r.view("a1." + s), ga1 = r.view("g.a1." + s);
+      View cat = r.view("cat." + s), gcat = r.view("g.cat." + s), gpool = r.view("g.pool." + s);
+      {
+        Scope sc(P, r.s, ("pool." + s + ".bwd").c_str(), 0, (double)B * H * W * f * 3.25 * esz(P));
+        sc.kernel("maxpool2_bwd");
+        RUN(launch_maxpool2_bwd(cat.p, cat.cs, 0, gpool.p, gpool.cs, 0, gcat.p, gcat.cs, 0, gcat.p, gcat.cs, 0, B, H, W,
+                                f, 1, dt, r.s));
+      }
+      View gy{gcat.p, gcat.cs, 0};
+      RUN(do_conv_wgrad(r, c2, a1, gy, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
+      RUN(do_conv_dgrad(r, c2, gy, ga1, &a1, B, H, W, (c2.prefix + ".dgrad").c_str()));
+      View xin = l == 0 ? r.view("x") : r.view("pool." + std::to_string(l - 1));
+      RUN(do_conv_wgrad(r, c1, xin, ga1, grads, alpha, beta, B, H, W, (c1.prefix + ".wgrad").c_str()));
+      if (l > 0) {
+        View gxin = r.view("g.pool." + std::to_string(l - 1));
+        RUN(do_conv_dgrad(r, c1, ga1, gxin, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
+      } else if (d.need_input_grad) {
+        View gx = r.view("g.x");
+        RUN(do_conv_dgrad(r, c1, ga1, gx, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
+        Scope sc(P, r.s, "input_grad_nchw", 0, (double)B * H * W * d.in_channels * (4 + esz(P)));
+        sc.kernel("nhwc_to_nchw");
+        RUN(launch_nhwc_to_nchw(gx.p, gx.cs, 0, dx_nchw, B, d.in_channels, H, W, dt, r.s));
+      }
+    }
+  }
+  return MI_OK;
+}
+
+}  // extern "C"

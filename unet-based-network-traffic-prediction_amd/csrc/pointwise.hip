@@ -1,0 +1,690 @@
+// Bandwidth-bound kernels of the U-Net hot path: layout changes, weight packing, 2x2
+// max-pool forward/backward, the 1x1 head, MSE, bilinear resize, Adam, and the
+// fixed-order combination of weight-gradient partials.  All are streaming kernels:
+// 16-byte vector accesses along the contiguous (channel) axis, grid-stride loops capped
+// at a few workgroups per CU, wavefront (64-lane) shuffles for reductions.
+#include "igemm_impl.h"
+
+namespace mi {
+
+static inline int grid_for(int64_t work_items, int block = 256, int max_blocks = 256 * 8) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+// ------------------------------------------------------------------------------------------
+// Layout: fp32 NCHW <-> NHWC view
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
+                                    int64_t npix, int C, int Cp, int HW) {
+  // one thread per (pixel, group of 4 channels); consecutive threads walk pixels so the
+  // NCHW reads are coalesced per channel plane.
+  const int groups = Cp / 4;
+  const int64_t total = npix * groups;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % npix;
+    const int g = (int)(i / npix);
+    const int64_t b = p / HW, r = p % HW;
+    f32x4_t v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = g * 4 + q;
+      v[q] = c < C ? src[(b * C + c) * HW + r] : 0.f;
+    }
+    store4f(dst + p * cs + co + g * 4, v);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int cs, int co, float* __restrict__ dst,
+                                    int64_t npix, int C, int HW) {
+  const int64_t total = npix * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i % npix;
+    const int c = (int)(i / npix);
+    const int64_t b = p / HW, r = p % HW;
+    dst[(b * C + c) * HW + r] = to_f(src[p * cs + co + c]);
+  }
+}
+int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype,
+                        hipStream_t s) {
+  const int64_t npix = (int64_t)B * H * W;
+  const int Cp = pad16(C);
+  const int grid = grid_for(npix * (Cp / 4));
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, npix, C, Cp, H * W);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, npix, C, Cp, H * W);
+  return check_hip(hipGetLastError(), "nchw_to_nhwc");
+}
+int launch_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W, int dtype,
+                        hipStream_t s) {
+  const int64_t npix = (int64_t)B * H * W;
+  const int grid = grid_for(npix * C);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, cs, co, dst, npix, C, H * W);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, cs, co, dst, npix, C, H * W);
+  return check_hip(hipGetLastError(), "nhwc_to_nchw");
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing.  One thread per packed element (the packed image is written exactly once,
+// zeros included, so the buffers never need a separate memset).
+__device__ __forceinline__ int unpos(int pos, int Cin, int split, int split_pad) {
+  // inverse of pos(ci): padded input-channel position -> logical channel or -1 (padding)
+  if (split > 0) {
+    if (pos < split_pad) return pos < split ? pos : -1;
+    const int c = split + (pos - split_pad);
+    return c < Cin ? c : -1;
+  }
+  return pos < Cin ? pos : -1;
+}
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
+                                    int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2) {
+  const int split_pad = (split + 15) / 16 * 16;
+  const int64_t nf = wf ? (int64_t)Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int n = (int)(i / Kp), k = (int)(i % Kp);
+      const int tap = k / Cp, pos = k % Cp;
+      float v = 0.f;
+      if (n < Cout && tap < 9) {
+        const int ci = unpos(pos, Cin, split, split_pad);
+        if (ci >= 0) v = w[((int64_t)n * Cin + ci) * 9 + tap];
+      }
+      wf[i] = from_f<T>(v);
+    } else {
+      const int64_t j = i - nf;
+      const int pos = (int)(j / Kp2), k = (int)(j % Kp2);
+      const int tap = k / Np, co = k % Np;
+      float v = 0.f;
+      if (tap < 9 && co < Cout) {
+        const int ci = unpos(pos, Cin, split, split_pad);
+        if (ci >= 0) v = w[((int64_t)co * Cin + ci) * 9 + (8 - tap)];
+      }
+      wb[j] = from_f<T>(v);
+    }
+  }
+}
+template <typename T>
+__global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
+                                     int Cin, int Cout, int Np, int Cp, int Kp, int Kp2) {
+  const int64_t nf = wf ? (int64_t)4 * Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int row = (int)(i / Kp), ci = (int)(i % Kp);
+      const int g = row / Np, co = row % Np;
+      float v = 0.f;
+      if (co < Cout && ci < Cin) v = w[((int64_t)ci * Cout + co) * 4 + g];
+      wf[i] = from_f<T>(v);
+    } else {
+      const int64_t j = i - nf;
+      const int ci = (int)(j / Kp2), k = (int)(j % Kp2);
+      const int g = k / Np, co = k % Np;
+      float v = 0.f;
+      if (ci < Cin && g < 4 && co < Cout) v = w[((int64_t)ci * Cout + co) * 4 + g];
+      wb[j] = from_f<T>(v);
+    }
+  }
+}
+int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype,
+                        hipStream_t s) {
+  const int Np = pad16(Cout), Cp = concat_cp(Cin, split);
+  const int Kp = (int)kpad(9 * Cp), Kp2 = (int)kpad(9 * Np);
+  const int64_t total = (wfwd ? (int64_t)Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
+  if (total == 0) return MI_OK;
+  const int grid = grid_for(total);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)wfwd, (__bf16*)wbwd, Cout, Cin, split, Np, Cp, Kp, Kp2);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)wfwd, (float*)wbwd, Cout, Cin, split, Np, Cp, Kp, Kp2);
+  return check_hip(hipGetLastError(), "pack_conv3x3");
+}
+int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, hipStream_t s) {
+  const int Np = pad16(Cout), Cp = pad16(Cin);
+  const int Kp = (int)kpad(Cp), Kp2 = (int)kpad(4 * Np);
+  const int64_t total = (wfwd ? (int64_t)4 * Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
+  if (total == 0) return MI_OK;
+  const int grid = grid_for(total);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(pack_convt2x2_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)wfwd, (__bf16*)wbwd, Cin, Cout, Np, Cp, Kp, Kp2);
+  else
+    hipLaunchKernelGGL(pack_convt2x2_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)wfwd, (float*)wbwd, Cin, Cout, Np, Cp, Kp, Kp2);
+  return check_hip(hipGetLastError(), "pack_convt2x2");
+}
+
+// ------------------------------------------------------------------------------------------
+// 2x2 max-pool.  One thread per (output pixel, 4-channel group).
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xcs, int xco, T* __restrict__ y, int ycs,
+                                    int yco, int B, int H, int W, int Cp) {
+  const int Ho = H / 2, Wo = W / 2, G = Cp / 4;
+  const int64_t total = (int64_t)B * Ho * Wo * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    const int64_t op = i / G;
+    const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho);
+    const int64_t b = op / ((int64_t)Wo * Ho);
+    const T* px = x + ((b * H + 2 * oy) * W + 2 * ox) * (int64_t)xcs + xco + g * 4;
+    const f32x4_t v00 = load4f(px), v01 = load4f(px + xcs), v10 = load4f(px + (int64_t)W * xcs),
+                  v11 = load4f(px + (int64_t)(W + 1) * xcs);
+    f32x4_t m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // PyTorch's update rule: take val if (val > max) or isnan(val), scanning row-major.
+      float mx = v00[q];
+      if (v01[q] > mx || v01[q] != v01[q]) mx = v01[q];
+      if (v10[q] > mx || v10[q] != v10[q]) mx = v10[q];
+      if (v11[q] > mx || v11[q] != v11[q]) mx = v11[q];
+      m[q] = mx;
+    }
+    store4f(y + op * ycs + yco + g * 4, m);
+  }
+}
+// One thread per (2x2 window incl. the partial windows of odd sizes, 4-channel group).
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dyp,
+                                    int pcs, int pco, const T* __restrict__ dskip, int scs, int sco,
+                                    T* __restrict__ dx, int dcs, int dco, int B, int H, int W, int Cp,
+                                    int relu_mask) {
+  const int Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2, G = Cp / 4;
+  const int64_t total = (int64_t)B * Hc * Wc * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    const int64_t wdx = i / G;
+    const int ox = (int)(wdx % Wc), oy = (int)((wdx / Wc) % Hc);
+    const int64_t b = wdx / ((int64_t)Wc * Hc);
+    const bool pooled = oy < Ho && ox < Wo;  // window produced a pooled output
+    f32x4_t xv[4], gv[4];
+    bool inb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+      inb[k] = yy < H && xx < W;
+      const int64_t pix = (b * H + yy) * W + xx;
+      xv[k] = inb[k] ? load4f(x + pix * xcs + xco + g * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      gv[k] = (inb[k] && dskip) ? load4f(dskip + pix * scs + sco + g * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    if (pooled) {
+      const f32x4_t gp = load4f(dyp + ((b * Ho + oy) * (int64_t)Wo + ox) * pcs + pco + g * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int arg = 0;
+        float mx = xv[0][q];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (xv[k][q] > mx || xv[k][q] != xv[k][q]) { mx = xv[k][q]; arg = k; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[k][q] += (k == arg) ? gp[q] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!inb[k]) continue;
+      f32x4_t o = gv[k];
+      if (relu_mask) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = xv[k][q] > 0.f ? o[q] : 0.f;
+      }
+      const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+      store4f(dx + ((b * H + yy) * W + xx) * (int64_t)dcs + dco + g * 4, o);
+    }
+  }
+}
+int launch_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C,
+                        int dtype, hipStream_t s) {
+  const int Cp = pad16(C);
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (Cp / 4);
+  if (total == 0) return MI_OK;
+  const int grid = grid_for(total);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, (__bf16*)y, ycs, yco, B, H, W, Cp);
+  else
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, (float*)y, ycs, yco, B, H, W, Cp);
+  return check_hip(hipGetLastError(), "maxpool2_fwd");
+}
+int launch_maxpool2_bwd(const void* x, int xcs, int xco, const void* dyp, int pcs, int pco, const void* dskip,
+                        int scs, int sco, void* dx, int dcs, int dco, int B, int H, int W, int C, int relu_mask,
+                        int dtype, hipStream_t s) {
+  const int Cp = pad16(C);
+  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (Cp / 4);
+  const int grid = grid_for(total);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, (const __bf16*)dyp, pcs, pco, (const __bf16*)dskip, scs, sco, (__bf16*)dx, dcs, dco, B, H, W, Cp, relu_mask);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, (const float*)dyp, pcs, pco, (const float*)dskip, scs, sco, (float*)dx, dcs, dco, B, H, W, Cp, relu_mask);
+  return check_hip(hipGetLastError(), "maxpool2_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// 1x1 head.  Cout is tiny (1 or 12): a per-pixel dot product, bandwidth-bound.
+constexpr int kHeadMaxCin = 64, kHeadMaxCout = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ pred, int64_t npix, int HW, int Cin,
+                                                        int Cp, int Cout) {
+  __shared__ float sw[kHeadMaxCout * kHeadMaxCin + kHeadMaxCout];
+  for (int i = threadIdx.x; i < Cout * Cp; i += blockDim.x) {
+    const int co = i / Cp, c = i % Cp;
+    sw[i] = c < Cin ? w[co * Cin + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * Cp + i] = bias[i];
+  __syncthreads();
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    float acc[kHeadMaxCout];
+#pragma unroll
+    for (int co = 0; co < kHeadMaxCout; ++co) acc[co] = 0.f;
+    const T* px = x + p * xcs + xco;
+    for (int c = 0; c < Cp; c += 4) {
+      const f32x4_t v = load4f(px + c);
+#pragma unroll
+      for (int co = 0; co < kHeadMaxCout; ++co)
+        if (co < Cout) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[co] = fmaf(v[q], sw[co * Cp + c + q], acc[co]);
+        }
+    }
+    const int64_t b = p / HW, r = p % HW;
+#pragma unroll
+    for (int co = 0; co < kHeadMaxCout; ++co)
+      if (co < Cout) pred[(b * Cout + co) * HW + r] = acc[co] + sw[Cout * Cp + co];
+  }
+}
+int launch_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,
+                    int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  MI_REQUIRE(pad16(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
+  const int64_t npix = (int64_t)B * H * W;
+  const int grid = grid_for(npix);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad16(Cin), Cout);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad16(Cin), Cout);
+  return check_hip(hipGetLastError(), "head_fwd");
+}
+
+// Head backward.  Phase 1 (thread = pixel): dx = (W^T dpred) * (x > 0); the pixel's dpred and
+// x values are parked in LDS.  Phase 2 (thread = (co, c) pair): accumulate dW over the 256
+// pixels of the tile.  Each workgroup walks several tiles and writes one partial.
+constexpr int kHeadTile = 256;
+constexpr int kHeadAcc = (kHeadMaxCout * kHeadMaxCin + kHeadMaxCout + 255) / 256;  // (co,c) pairs per thread
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                        const float* __restrict__ w, const float* __restrict__ dpred,
+                                                        T* __restrict__ dx, int dcs, int dco, float* __restrict__ part,
+                                                        int64_t npix, int HW, int Cin, int Cp, int Cout, int relu_mask) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* sw = sh;                              // [Cout][Cp]
+  float* sx = sw + Cout * Cp;                  // [kHeadTile][Cp + 1]
+  float* sg = sx + kHeadTile * (Cp + 1);       // [kHeadTile][Cout]
+  for (int i = threadIdx.x; i < Cout * Cp; i += blockDim.x) {
+    const int co = i / Cp, c = i % Cp;
+    sw[i] = c < Cin ? w[co * Cin + c] : 0.f;
+  }
+  const int npairs = Cout * Cp + Cout;         // dW pairs then db entries
+  float accp[kHeadAcc];
+#pragma unroll
+  for (int i = 0; i < kHeadAcc; ++i) accp[i] = 0.f;
+  __syncthreads();
+  const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p = tile * kHeadTile + threadIdx.x;
+    const bool ok = p < npix;
+    float g[kHeadMaxCout];
+    const int64_t b = ok ? p / HW : 0, r = ok ? p % HW : 0;
+#pragma unroll
+    for (int co = 0; co < kHeadMaxCout; ++co) {
+      g[co] = (ok && co < Cout) ? dpred[(b * Cout + co) * HW + r] : 0.f;
+      if (co < Cout) sg[threadIdx.x * Cout + co] = g[co];
+    }
+    for (int c = 0; c < Cp; c += 4) {
+      f32x4_t xv = {0.f, 0.f, 0.f, 0.f};
+      if (ok) xv = load4f(x + p * xcs + xco + c);
+      f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int co = 0; co < kHeadMaxCout; ++co)
+        if (co < Cout) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) d[q] = fmaf(g[co], sw[co * Cp + c + q], d[q]);
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (relu_mask && !(xv[q] > 0.f)) d[q] = 0.f;
+        sx[threadIdx.x * (Cp + 1) + c + q] = xv[q];
+      }
+      if (ok) store4f(dx + p * dcs + dco + c, d);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kHeadAcc; ++k) {
+      const int pr = threadIdx.x + 256 * k;
+      if (pr >= npairs) continue;
+      float s = 0.f;
+      if (pr < Cout * Cp) {
+        const int co = pr / Cp, c = pr % Cp;
+        for (int i = 0; i < kHeadTile; ++i) s = fmaf(sg[i * Cout + co], sx[i * (Cp + 1) + c], s);
+      } else {
+        const int co = pr - Cout * Cp;
+        for (int i = 0; i < kHeadTile; ++i) s += sg[i * Cout + co];
+      }
+      accp[k] += s;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < kHeadAcc; ++k) {
+    const int pr = threadIdx.x + 256 * k;
+    if (pr < npairs) part[(int64_t)blockIdx.x * npairs + pr] = accp[k];
+  }
+}
+__global__ void head_finalize_kernel(const float* __restrict__ part, int nblocks, int Cin, int Cp, int Cout,
+                                     float* __restrict__ dW, float* __restrict__ db, float alpha, float beta) {
+  const int npairs = Cout * Cp + Cout;
+  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pr >= npairs) return;
+  float s = 0.f;
+  for (int i = 0; i < nblocks; ++i) s += part[(int64_t)i * npairs + pr];
+  if (pr < Cout * Cp) {
+    const int co = pr / Cp, c = pr % Cp;
+    if (c < Cin) {
+      float* o = dW + co * Cin + c;
+      *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
+    }
+  } else {
+    float* o = db + (pr - Cout * Cp);
+    *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
+  }
+}
+constexpr int kHeadBlocks = 512;
+size_t head_ws_bytes(int Cin, int Cout) { return (size_t)kHeadBlocks * (Cout * pad16(Cin) + Cout) * sizeof(float); }
+int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float* dpred, void* dx, int dcs, int dco,
+                    float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W,
+                    int Cin, int Cout, int relu_mask, int dtype, hipStream_t s) {
+  MI_REQUIRE(pad16(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
+  if (ws_bytes < head_ws_bytes(Cin, Cout)) return fail(MI_ESIZE, "head_bwd: workspace too small");
+  const int Cp = pad16(Cin);
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
+  const int nblocks = (int)(ntiles < kHeadBlocks ? ntiles : kHeadBlocks);
+  const size_t shm = (size_t)(Cout * Cp + kHeadTile * (Cp + 1) + kHeadTile * Cout) * sizeof(float);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(head_bwd_kernel<__bf16>, dim3(nblocks), dim3(256), shm, s, (const __bf16*)x, xcs, xco, w, dpred, (__bf16*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, Cp, Cout, relu_mask);
+  else
+    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nblocks), dim3(256), shm, s, (const float*)x, xcs, xco, w, dpred, (float*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, Cp, Cout, relu_mask);
+  int rc = check_hip(hipGetLastError(), "head_bwd");
+  if (rc) return rc;
+  const int npairs = Cout * Cp + Cout;
+  hipLaunchKernelGGL(head_finalize_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, (const float*)ws, nblocks, Cin, Cp, Cout, dW, db, alpha, beta);
+  return check_hip(hipGetLastError(), "head_finalize");
+}
+
+// ------------------------------------------------------------------------------------------
+// MSE: per-workgroup partial sums (wave shuffle -> LDS), then one small fixed-order pass.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                           int64_t n, float* __restrict__ dpred, float coef,
+                                                           const float* __restrict__ gdev, float* __restrict__ part) {
+  float sq = 0.f, ab = 0.f;
+  const float c = coef * (gdev ? *gdev : 1.f);
+  const int64_t n4 = n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4_t p = *(const f32x4_t*)(pred + 4 * i), y = *(const f32x4_t*)(tgt + 4 * i);
+    f32x4_t d = p - y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sq = fmaf(d[q], d[q], sq); ab += fabsf(d[q]); }
+    if (dpred) { d *= c; *(f32x4_t*)(dpred + 4 * i) = d; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    const float d = pred[i] - tgt[i];
+    sq = fmaf(d, d, sq); ab += fabsf(d);
+    if (dpred) dpred[i] = d * c;
+  }
+  __shared__ float s1[4], s2[4];
+  sq = wave_sum(sq); ab = wave_sum(ab);
+  if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = sq; s2[threadIdx.x >> 6] = ab; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+    part[2 * blockIdx.x + 1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+  }
+}
+__global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__ part, int nblocks, double inv_n,
+                                                        float* __restrict__ out3) {
+  // one wave; double accumulation keeps the reported loss within an ulp of the exact mean
+  double sq = 0.0, ab = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { sq += part[2 * i]; ab += part[2 * i + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sq += __shfl_down(sq, o, 64); ab += __shfl_down(ab, o, 64); }
+  if (threadIdx.x == 0) { out3[0] = (float)(sq * inv_n); out3[1] = (float)ab; out3[2] = (float)sq; }
+}
+constexpr int kMseBlocks = 1024;
+size_t mse_ws_bytes(int64_t) { return (size_t)kMseBlocks * 2 * sizeof(float); }
+int launch_mse(const float* pred, const float* target, int64_t n, float* out3, float* dpred, float gscale,
+               const float* gscale_dev, void* ws, size_t ws_bytes, hipStream_t s) {
+  MI_REQUIRE(n > 0, "mse: empty input");
+  if (ws_bytes < mse_ws_bytes(n)) return fail(MI_ESIZE, "mse: workspace too small");
+  MI_REQUIRE(((uintptr_t)pred % 16 == 0) && ((uintptr_t)target % 16 == 0) && ((uintptr_t)dpred % 16 == 0),
+             "mse: pointers must be 16-byte aligned");
+  int nblocks = (int)((n / 4 + 255) / 256);
+  if (nblocks < 1) nblocks = 1;
+  if (nblocks > kMseBlocks) nblocks = kMseBlocks;
+  const float coef = gscale * 2.0f / (float)n;
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(nblocks), dim3(256), 0, s, pred, target, n, dpred, coef, gscale_dev, (float*)ws);
+  int rc = check_hip(hipGetLastError(), "mse_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, nblocks, 1.0 / (double)n, out3);
+  return check_hip(hipGetLastError(), "mse_final");
+}
+
+// ------------------------------------------------------------------------------------------
+// Bilinear resize, align_corners=False (half-pixel centres, source index clamped at 0).
+__device__ __forceinline__ void bil_src(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+__device__ __forceinline__ float ld_any(const void* p, int64_t off, int dt) {
+  return dt == MI_BF16 ? (float)((const __bf16*)p)[off] : ((const float*)p)[off];
+}
+__device__ __forceinline__ void st_any(void* p, int64_t off, int dt, float v) {
+  if (dt == MI_BF16) ((__bf16*)p)[off] = (__bf16)v; else ((float*)p)[off] = v;
+}
+__global__ void bilinear_fwd_kernel(const void* __restrict__ src, int64_t ssb, int64_t ssc, int64_t ssy, int64_t ssx,
+                                    int sdt, void* __restrict__ dst, int64_t dsb, int64_t dsc, int64_t dsy,
+                                    int64_t dsx, int ddt, int B, int C, int Hin, int Win, int Hout, int Wout,
+                                    float sh, float sw, int c_fastest) {
+  const int64_t total = (int64_t)B * C * Hout * Wout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c, ox, oy; int64_t b;
+    if (c_fastest) { c = (int)(i % C); int64_t r = i / C; ox = (int)(r % Wout); r /= Wout; oy = (int)(r % Hout); b = r / Hout; }
+    else { ox = (int)(i % Wout); int64_t r = i / Wout; oy = (int)(r % Hout); r /= Hout; c = (int)(r % C); b = r / C; }
+    int y0, y1, x0, x1; float ly, lx;
+    bil_src(oy, sh, Hin, y0, y1, ly);
+    bil_src(ox, sw, Win, x0, x1, lx);
+    const int64_t base = b * ssb + c * ssc;
+    const float v00 = ld_any(src, base + y0 * ssy + x0 * ssx, sdt), v01 = ld_any(src, base + y0 * ssy + x1 * ssx, sdt);
+    const float v10 = ld_any(src, base + y1 * ssy + x0 * ssx, sdt), v11 = ld_any(src, base + y1 * ssy + x1 * ssx, sdt);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    st_any(dst, b * dsb + c * dsc + oy * dsy + ox * dsx, ddt, v);
+  }
+}
+// Gather form of the backward: each input element sums the output gradients that read it.
+__global__ void bilinear_bwd_kernel(const void* __restrict__ dout, int64_t osb, int64_t osc, int64_t osy, int64_t osx,
+                                    int odt, void* __restrict__ din, int64_t isb, int64_t isc, int64_t isy,
+                                    int64_t isx, int idt, int B, int C, int Hin, int Win, int Hout, int Wout,
+                                    float sh, float sw, int c_fastest) {
+  const int64_t total = (int64_t)B * C * Hin * Win;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c, ix, iy; int64_t b;
+    if (c_fastest) { c = (int)(i % C); int64_t r = i / C; ix = (int)(r % Win); r /= Win; iy = (int)(r % Hin); b = r / Hin; }
+    else { ix = (int)(i % Win); int64_t r = i / Win; iy = (int)(r % Hin); r /= Hin; c = (int)(r % C); b = r / C; }
+    // candidate output rows/cols: those whose source index lies in [iy-1, iy+1)
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    if (oy_lo < 0) oy_lo = 0; if (ox_lo < 0) ox_lo = 0;
+    if (oy_hi > Hout - 1) oy_hi = Hout - 1; if (ox_hi > Wout - 1) ox_hi = Wout - 1;
+    float acc = 0.f;
+    const int64_t base = b * osb + c * osc;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      bil_src(oy, sh, Hin, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        bil_src(ox, sw, Win, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx == 0.f) continue;
+        acc = fmaf(wy * wx, ld_any(dout, base + oy * osy + ox * osx, odt), acc);
+      }
+    }
+    st_any(din, b * isb + c * isc + iy * isy + ix * isx, idt, acc);
+  }
+}
+int launch_bilinear_fwd(const void* src, int64_t ssb, int64_t ssc, int64_t ssy, int64_t ssx, int sdt, void* dst,
+                        int64_t dsb, int64_t dsc, int64_t dsy, int64_t dsx, int ddt, int B, int C, int Hin, int Win,
+                        int Hout, int Wout, hipStream_t s) {
+  const int64_t total = (int64_t)B * C * Hout * Wout;
+  if (total == 0) return MI_OK;
+  const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, ssb, ssc, ssy, ssx, sdt, dst, dsb,
+                     dsc, dsy, dsx, ddt, B, C, Hin, Win, Hout, Wout, sh, sw, dsc == 1 ? 1 : 0);
+  return check_hip(hipGetLastError(), "bilinear_fwd");
+}
+int launch_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy, int64_t osx, int odt, void* din,
+                        int64_t isb, int64_t isc, int64_t isy, int64_t isx, int idt, int B, int C, int Hin, int Win,
+                        int Hout, int Wout, hipStream_t s) {
+  const int64_t total = (int64_t)B * C * Hin * Win;
+  if (total == 0) return MI_OK;
+  const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dout, osb, osc, osy, osx, odt, din, isb,
+                     isc, isy, isx, idt, B, C, Hin, Win, Hout, Wout, sh, sw, isc == 1 ? 1 : 0);
+  return check_hip(hipGetLastError(), "bilinear_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam over a flat range (torch.optim.Adam defaults: no weight decay, no amsgrad).
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
+                            float inv_bc2_sqrt, float gs) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4_t pv = *(f32x4_t*)(p + 4 * i), gv = *(const f32x4_t*)(g + 4 * i), mv = *(f32x4_t*)(m + 4 * i),
+            vv = *(f32x4_t*)(v + 4 * i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float gq = gv[q] * gs;
+      mv[q] = mv[q] + (gq - mv[q]) * (1.f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+      vv[q] = vv[q] * b2 + (1.f - b2) * gq * gq;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+      const float denom = sqrtf(vv[q]) * inv_bc2_sqrt + eps;
+      pv[q] = pv[q] - step_size * (mv[q] / denom);
+    }
+    *(f32x4_t*)(p + 4 * i) = pv; *(f32x4_t*)(m + 4 * i) = mv; *(f32x4_t*)(v + 4 * i) = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    const float gq = g[i] * gs;
+    const float mq = m[i] + (gq - m[i]) * (1.f - b1);
+    const float vq = v[i] * b2 + (1.f - b2) * gq * gq;
+    m[i] = mq; v[i] = vq;
+    p[i] = p[i] - step_size * (mq / (sqrtf(vq) * inv_bc2_sqrt + eps));
+  }
+}
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                int step, float grad_scale, hipStream_t s) {
+  MI_REQUIRE(step >= 1 && n >= 0, "adam: step must be >= 1");
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+             "adam: pointers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, step_size,
+                     inv_bc2_sqrt, grad_scale);
+  return check_hip(hipGetLastError(), "adam");
+}
+
+// ------------------------------------------------------------------------------------------
+// Fixed-order combination of weight-gradient partials into the reference's parameter layout.
+__global__ void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum, int splits,
+                                      int Npad, int Cp, int Cout, int Cin, int split, float* __restrict__ dW,
+                                      float* __restrict__ db, float alpha, float beta) {
+  // thread per (co, k) with k fastest: coalesced partial reads, strided (x9) writes
+  const int K = 9 * Cp;
+  const int split_pad = (split + 15) / 16 * 16;
+  const int64_t total = (int64_t)Cout * K + Cout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < (int64_t)Cout * K) {
+      const int co = (int)(i / K), k = (int)(i % K);
+      const int tap = k / Cp, pos = k % Cp;
+      const int ci = unpos(pos, Cin, split, split_pad);
+      if (ci < 0) continue;
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += part[((int64_t)z * Npad + co) * K + k];
+      float* o = dW + ((int64_t)co * Cin + ci) * 9 + tap;
+      *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
+    } else if (db != nullptr) {
+      const int co = (int)(i - (int64_t)Cout * K);
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += rowsum[(int64_t)z * Npad + co];
+      db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+    }
+  }
+}
+__global__ void finalize_convt_kernel(const float* __restrict__ part, const float* __restrict__ colsum, int splits,
+                                      int Cp_in, int Npad, int Cin, int Cout, float* __restrict__ dW,
+                                      float* __restrict__ db, float alpha, float beta) {
+  const int K = 4 * Npad;
+  const int64_t total = (int64_t)Cin * K + Cout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < (int64_t)Cin * K) {
+      const int ci = (int)(i / K), k = (int)(i % K);
+      const int g = k / Npad, co = k % Npad;
+      if (co >= Cout) continue;
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z) s += part[((int64_t)z * Cp_in + ci) * K + k];
+      float* o = dW + ((int64_t)ci * Cout + co) * 4 + g;
+      *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
+    } else if (db != nullptr) {
+      const int co = (int)(i - (int64_t)Cin * K);
+      float s = 0.f;
+      for (int z = 0; z < splits; ++z)
+        for (int g = 0; g < 4; ++g) s += colsum[(int64_t)z * K + g * Npad + co];
+      db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+    }
+  }
+}
+int launch_finalize_conv3(const float* part, const float* rowsum, int splits, int Npad, int Cp, int Cout, int Cin,
+                          int split, float* dW, float* db, float alpha, float beta, hipStream_t s) {
+  const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
+  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total)), dim3(256), 0, s, part, rowsum, splits, Npad, Cp, Cout,
+                     Cin, split, dW, db, alpha, beta);
+  return check_hip(hipGetLastError(), "finalize_conv3");
+}
+int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin, int Cout,
+                          float* dW, float* db, float alpha, float beta, hipStream_t s) {
+  const int64_t total = (int64_t)Cin * 4 * Npad + Cout;
+  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total)), dim3(256), 0, s, part, colsum, splits, Cp_in, Npad,
+                     Cin, Cout, dW, db, alpha, beta);
+  return check_hip(hipGetLastError(), "finalize_convt");
+}
+
+}  // namespace mi

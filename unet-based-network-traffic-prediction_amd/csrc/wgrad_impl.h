@@ -1,0 +1,256 @@
+// Weight-gradient kernel for gfx950: the autograd backward of the reference's Conv2d /
+// ConvTranspose2d layers (models/unet2d.py:28-31, :46-48) with respect to their weights.
+//
+//   part[z][n][k] = sum_{p in pixel range z} a[p][n] * b[gather(p, tap)][c],  k = tap*Cb + c
+//
+// GEMM view: the reduction runs over PIXELS, the slow index of both NHWC operands, so
+// the LDS tiles stay [pixel][64 channels] as loaded and the MFMA fragments are read
+// transposed: ds_read_b64_tr_b16 for bf16 (4 pixels x 16 channels per 16-lane group),
+// plain ds_read_b32 for fp32 (v_mfma_f32_16x16x4_f32 wants one float per lane).
+// One workgroup owns a 64(n) x 64(k) output tile for one pixel range; ranges are
+// combined afterwards in a fixed order (bitwise reproducible, no atomics).
+// Row sums of a (bias gradient of a conv) and column sums of b (bias gradient of a
+// transposed conv) come from extra MFMAs against an all-ones fragment.
+#pragma once
+#include "igemm_impl.h"
+
+namespace mi {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <typename T> struct WgTraits;
+template <> struct WgTraits<__bf16> {
+  static constexpr int PB = 128;   // pixels per stage
+  static constexpr int ROWB = 128; // bytes per LDS row (64 channels)
+};
+template <> struct WgTraits<float> {
+  static constexpr int PB = 64;
+  static constexpr int ROWB = 256;
+};
+
+// Byte offset of 16-byte chunk q of row r inside a [rows][64 ch] tile.
+// bf16 (128-B rows): the 32-byte column group is XORed with bits 1 and 3 of the row, which
+// spreads the 8 rows {r..r+3, r+8..r+11} one transposed read touches over all 64 banks.
+// fp32 (256-B rows): the 64-byte column group is XORed with bit 0 of the row (two
+// consecutive rows per ds_read_b32 half-wave).
+template <typename T> __device__ __forceinline__ int tile_off(int r, int q);
+template <> __device__ __forceinline__ int tile_off<__bf16>(int r, int q) {
+  const int f = ((r >> 1) & 1) | (((r >> 3) & 1) << 1);
+  return r * 128 + (((((q >> 1) ^ f) << 1) | (q & 1)) << 4);
+}
+template <> __device__ __forceinline__ int tile_off<float>(int r, int q) {
+  return r * 256 + (((((q >> 2) ^ (r & 1)) << 2) | (q & 3)) << 4);
+}
+
+// Fragment of tile column block `ct` (16 channels) for the MFMA k-step `ks`.
+// bf16: k-step = 32 pixels; lane (g = lane>>4, i = lane&15) ends up with channel ct*16+i of
+//       pixels ks*32 + 8g + 0..7.
+__device__ __forceinline__ bf16x8_t read_frag_tr(const char* tile, int ks, int ct, int lane, __bf16) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+  const int r0 = ks * 32 + 8 * g + q;
+  const int chunk = 2 * ct + (pp >> 1);
+  const int sub = (pp & 1) * 8;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + tile_off<__bf16>(r0, chunk) + sub));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + tile_off<__bf16>(r0 + 4, chunk) + sub));
+  union { s16x4_t s[2]; bf16x8_t v; } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.v;
+}
+// fp32: k-step = 4 pixels; lane holds channel ct*16 + (lane&15) of pixel ks*4 + (lane>>4).
+__device__ __forceinline__ float read_frag_tr(const char* tile, int ks, int ct, int lane, float) {
+  const int r = ks * 4 + (lane >> 4), c = ct * 16 + (lane & 15);
+  return *(const float*)(tile + tile_off<float>(r, c >> 2) + (c & 3) * 4);
+}
+
+__device__ __forceinline__ f32x4_t mma_px(const bf16x8_t& a, const bf16x8_t& b, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mma_px(float a, float b, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8_t ones_frag(__bf16) {
+  const __bf16 o = (__bf16)1.0f;
+  return bf16x8_t{o, o, o, o, o, o, o, o};
+}
+__device__ __forceinline__ float ones_frag(float) { return 1.0f; }
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  constexpr int EPC = ElemTraits<T>::EPC;
+  constexpr int PB = WgTraits<T>::PB;
+  constexpr int CPR = 64 / EPC;           // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR;          // rows per loader pass
+  constexpr int IT = PB / RPP;            // chunks per thread per operand per stage
+  constexpr int TILE = PB * WgTraits<T>::ROWB;
+  constexpr int KSTEPS = PB / (sizeof(T) == 2 ? 32 : 4);
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // 2 stages x (a tile, b tile)
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, z = blockIdx.z;
+  const int K = a.taps * a.Cb;
+  const T* __restrict__ pa = (const T*)a.a;
+  const T* __restrict__ pb = (const T*)a.b;
+  const int HW = a.Ho * a.Wo;
+  const int pbeg = z * a.pix_per_split;
+  const int pend = min(a.M, pbeg + a.pix_per_split);
+
+  const int cch = t % CPR, row0 = t / CPR;
+  // a-operand chunk: channels n0 + cch*EPC ..
+  const int an = n0 + cch * EPC;
+  const bool a_ok = an < a.Na;
+  // b-operand chunk: k = k0 + cch*EPC -> (tap, c), fixed for the whole kernel
+  const int bk = k0 + cch * EPC;
+  const int btap = bk / a.Cb, bc = bk - btap * a.Cb;
+  const bool b_ok = bk < K;
+  int dy = 0, dx = 0;
+  int64_t toff = 0;
+  if (MODE == G_3x3) {
+    const int ty = btap / 3;
+    dy = ty - 1;
+    dx = btap - ty * 3 - 1;
+    toff = (int64_t)(dy * a.Wb + dx) * a.b_cs;
+  } else if (MODE == G_2x2S2) {
+    toff = (int64_t)((btap >> 1) * a.Wb + (btap & 1)) * a.b_cs;
+  }
+  toff += a.b_co + bc;
+
+  uint4 ra[IT], rb[IT];
+  auto load_stage = [&](int pstage) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int p = pstage + row0 + i * RPP;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (p < pend) {
+        if (a_ok) va = *(const uint4*)(pa + (int64_t)p * a.a_cs + a.a_co + an);
+        if (b_ok) {
+          if (MODE == G_1x1) {
+            vb = *(const uint4*)(pb + (int64_t)p * a.b_cs + toff);
+          } else {
+            const uint32_t b = fdiv((uint32_t)p, a.divHW);
+            const uint32_t r = (uint32_t)p - b * (uint32_t)HW;
+            const uint32_t y = fdiv(r, a.divW);
+            const uint32_t x = r - y * (uint32_t)a.Wo;
+            if (MODE == G_3x3) {
+              if ((unsigned)((int)y + dy) < (unsigned)a.Hb && (unsigned)((int)x + dx) < (unsigned)a.Wb)
+                vb = *(const uint4*)(pb + (int64_t)p * a.b_cs + toff);
+            } else {
+              vb = *(const uint4*)(pb + ((int64_t)(b * a.Hb + 2 * y) * a.Wb + 2 * x) * a.b_cs + toff);
+            }
+          }
+        }
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    char* At = smem + buf * 2 * TILE;
+    char* Bt = At + TILE;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int row = row0 + i * RPP;
+      *(uint4*)(At + tile_off<T>(row, cch)) = ra[i];
+      *(uint4*)(Bt + tile_off<T>(row, cch)) = rb[i];
+    }
+  };
+
+  f32x4_t acc[2][2], accr[2], accc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    accr[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    accc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_rows = a.rowsum != nullptr && blockIdx.y == 0 && wc == 0;
+  const bool do_cols = a.colsum != nullptr && blockIdx.x == 0 && wr == 0;
+  const auto ones = ones_frag(T());
+
+  auto compute = [&](int buf) {
+    const char* At = smem + buf * 2 * TILE;
+    const char* Bt = At + TILE;
+#pragma unroll 4
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const auto a0 = read_frag_tr(At, ks, 2 * wr, lane, T());
+      const auto a1 = read_frag_tr(At, ks, 2 * wr + 1, lane, T());
+      const auto b0 = read_frag_tr(Bt, ks, 2 * wc, lane, T());
+      const auto b1 = read_frag_tr(Bt, ks, 2 * wc + 1, lane, T());
+      acc[0][0] = mma_px(a0, b0, acc[0][0]);
+      acc[0][1] = mma_px(a0, b1, acc[0][1]);
+      acc[1][0] = mma_px(a1, b0, acc[1][0]);
+      acc[1][1] = mma_px(a1, b1, acc[1][1]);
+      if (do_rows) {
+        accr[0] = mma_px(a0, ones, accr[0]);
+        accr[1] = mma_px(a1, ones, accr[1]);
+      }
+      if (do_cols) {
+        accc[0] = mma_px(ones, b0, accc[0]);
+        accc[1] = mma_px(ones, b1, accc[1]);
+      }
+    }
+  };
+
+  const int nst = (pend - pbeg + PB - 1) / PB;
+  if (nst > 0) {
+    load_stage(pbeg);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      const bool more = st + 1 < nst;
+      if (more) load_stage(pbeg + (st + 1) * PB);
+      compute(st & 1);
+      if (more) store_stage((st + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // D layout: row (= n) = 4*(lane>>4) + j, col (= k) = lane & 15.
+  const int rq = 4 * (lane >> 4), cq = lane & 15;
+  float* part = a.part + (int64_t)z * a.Na * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + (2 * wc + j) * 16 + cq;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + (2 * wr + i) * 16 + rq + q;
+        if (n < a.Na && k < K) part[(int64_t)n * K + k] = acc[i][j][q];
+      }
+    }
+  if (do_rows && cq == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + (2 * wr + i) * 16 + rq + q;
+        if (n < a.Na) a.rowsum[(int64_t)z * a.Na + n] = accr[i][q];
+      }
+  }
+  if (do_cols && rq == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + (2 * wc + j) * 16 + cq;
+      if (k < K) a.colsum[(int64_t)z * K + k] = accc[j][0];
+    }
+  }
+}
+
+template <typename T>
+static int launch_wgrad_t(const WgradArgs& a, hipStream_t s, const char** name) {
+  const int K = a.taps * a.Cb;
+  dim3 grid((a.Na + 63) / 64, (K + 63) / 64, a.splits);
+  if (name) *name = "wgrad_64x64";
+  switch (a.mode) {
+    case G_3x3: hipLaunchKernelGGL((wgrad_kernel<T, G_3x3>), grid, dim3(256), 0, s, a); break;
+    case G_2x2S2: hipLaunchKernelGGL((wgrad_kernel<T, G_2x2S2>), grid, dim3(256), 0, s, a); break;
+    case G_1x1: hipLaunchKernelGGL((wgrad_kernel<T, G_1x1>), grid, dim3(256), 0, s, a); break;
+    default: return fail(MI_EINVAL, "wgrad: bad gather mode");
+  }
+  return check_hip(hipGetLastError(), "wgrad launch");
+}
+
+}  // namespace mi

@@ -1,0 +1,133 @@
+"""Data-parallel training: one process per GPU, gradients averaged across ranks.
+
+The reference is single-device (train.py:420-423, :495); this is the one collective the
+path needs.  Samples are independent (the network has no cross-sample statistics), so
+rank r simply takes rows [r*B/W, (r+1)*B/W) of the global batch and the per-rank MSE
+means average to the global-batch mean: gradients are SUMMED across ranks after each
+rank's are scaled by 1/world_size (folded into the weight-gradient kernels' alpha).
+
+Bucketing.  Backward runs in segments whose flat gradient ranges are contiguous and
+descend through one flat fp32 buffer (parameters are laid out in forward order), so a
+bucket is a run of consecutive segments = one contiguous slice.  As soon as a bucket's
+kernels are enqueued its all-reduce is started with ``async_op=True``: the process
+group's communication stream waits for the compute stream at that point and the
+collective overlaps with the remaining backward kernels.  Over xGMI (point-to-point
+links) a ring all-reduce is bound by one link, so buckets are few and large (default
+8 MiB) and the tiny early-encoder tail rides in the last bucket.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
+    ``backend`` defaults to "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".
+    Returns (rank, world_size, local_rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(X: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rows of the global batch owned by ``rank`` (even split; the global batch must divide)."""
+    if X.shape[0] % world != 0:
+        raise ValueError(f"global batch {X.shape[0]} is not divisible by world size {world}")
+    per = X.shape[0] // world
+    return X[rank * per:(rank + 1) * per]
+
+
+def plan_buckets(segments: List[Tuple[int, int]], bucket_bytes: int) -> List[Tuple[int, int, int, int]]:
+    """Group consecutive backward segments into buckets of at least ``bucket_bytes``.
+
+    ``segments[s] = (lo, hi)`` are flat element ranges in execution order (descending).
+    Returns [(seg_lo, seg_hi, lo, hi)]: segments [seg_lo, seg_hi) form one bucket covering
+    flat elements [lo, hi)."""
+    buckets = []
+    start = 0
+    while start < len(segments):
+        end = start + 1
+        while end < len(segments) and (segments[start][1] - segments[end - 1][0]) * 4 < bucket_bytes:
+            end += 1
+        lo = min(s[0] for s in segments[start:end])
+        hi = max(s[1] for s in segments[start:end])
+        buckets.append((start, end, lo, hi))
+        start = end
+    # a small trailing bucket is merged into its predecessor (one fewer exposed collective)
+    if len(buckets) >= 2 and (buckets[-1][3] - buckets[-1][2]) * 4 < bucket_bytes // 4:
+        a, b = buckets[-2], buckets[-1]
+        buckets[-2:] = [(a[0], b[1], min(a[2], b[2]), max(a[3], b[3]))]
+    return buckets
+
+
+class GradientReducer:
+    """Averages a flat gradient buffer across the process group, bucket by bucket."""
+
+    def __init__(self, process_group=None, bucket_bytes: int = 8 << 20):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_bytes = bucket_bytes
+        self.grad_prescale = 1.0 / self.world
+        self._pending = []
+        self._bucket_cache = {}
+
+    def attach(self, model) -> "GradientReducer":
+        model._dp = self if self.world > 1 else None
+        return self
+
+    def buckets_for(self, plan) -> List[Tuple[int, int, int, int]]:
+        key = id(plan)
+        b = self._bucket_cache.get(key)
+        if b is None:
+            b = plan_buckets(plan.segments, self.bucket_bytes)
+            self._bucket_cache[key] = b
+        return b
+
+    def reduce_async(self, flat_slice: torch.Tensor) -> None:
+        if self.world > 1:
+            self._pending.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait_all(self) -> None:
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+
+    def reduce_flat(self, flat: torch.Tensor, segments: List[Tuple[int, int]], prescaled: bool = False) -> None:
+        """Synchronous form used by tests and by callers that computed gradients elsewhere:
+        average ``flat`` in place, bucket by bucket."""
+        if self.world == 1:
+            return
+        if not prescaled:
+            flat.mul_(self.grad_prescale)
+        for (_, _, lo, hi) in plan_buckets(segments, self.bucket_bytes):
+            self.reduce_async(flat[lo:hi])
+        self.wait_all()
+
+
+def broadcast_parameters(model, src: int = 0, group=None) -> None:
+    """Make every rank start from rank ``src``'s parameters (one broadcast of the flat buffer
+    when the model has one, else per tensor)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = getattr(model, "_flat", None)
+    if flat is not None:
+        dist.broadcast(flat, src=src, group=group)
+        model.mark_parameters_changed()
+    else:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=src, group=group)

@@ -1,0 +1,316 @@
+"""Drop-in ``UNet`` whose forward and backward run as hand-written gfx950 HIP kernels.
+
+Same constructor, parameter names, shapes, initialisation and call signature as the
+reference ``UNet`` (models/unet2d.py:8-102; the class the reference factory actually
+builds is the identical copy at models/cells.py:425-519).  What differs is everything
+under ``forward``: the module holds no compute of its own -- one C call enqueues the
+whole forward launch sequence, one (segmented) C call the whole backward.
+
+Memory model
+  * all parameters are views into ONE flat fp32 buffer (construction order, 64-element
+    aligned) so the optimiser step and the data-parallel gradient reduction run over
+    contiguous ranges;
+  * each (batch, H, W) shape gets a plan and a workspace holding every activation, every
+    activation gradient, the packed MFMA weight operands and the weight-gradient partials;
+  * gradients of a backward pass land in one flat fp32 buffer, handed to autograd as views.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .._lib import MI_FWD_REPACK, MI_FWD_TRAIN, UNetDesc, check, lib
+from ..ops import mi_dtype, torch_dtype
+
+DEFAULT_COMPUTE_DTYPE = os.environ.get("UNET_TM_DTYPE", "bf16")
+
+
+class _Plan:
+    """Shape-specific launch plan plus the workspace it runs in."""
+
+    def __init__(self, model: "UNet", B: int, H: int, W: int, device: torch.device, need_input_grad: bool):
+        L = lib()
+        d = UNetDesc()
+        d.in_channels, d.out_channels = model.in_channels, model.out_channels
+        d.n_levels = len(model.features)
+        for i, f in enumerate(model.features):
+            d.features[i] = f
+        d.batch, d.height, d.width = B, H, W
+        d.out_h, d.out_w = model.out_size if model.out_size is not None else (0, 0)
+        d.dtype = mi_dtype(model.compute_dtype)
+        d.need_input_grad = int(need_input_grad)
+        handle = C.c_void_p()
+        check(L.mi_unet_plan_create(C.byref(d), C.byref(handle)), "plan_create")
+        self.handle = handle
+        self.B, self.H, self.W = B, H, W
+        self.need_input_grad = bool(need_input_grad)
+        self.ws_bytes = L.mi_unet_plan_workspace_bytes(handle)
+        self.ws = torch.empty(self.ws_bytes, device=device, dtype=torch.uint8)
+        self.out_hw = model.out_size if model.out_size is not None else (H, W)
+        self.n_segments = L.mi_unet_plan_num_segments(handle)
+        self.segments = []
+        for s in range(self.n_segments):
+            lo, hi = C.c_int64(), C.c_int64()
+            check(L.mi_unet_plan_segment_range(handle, s, C.byref(lo), C.byref(hi)), "segment_range")
+            self.segments.append((lo.value, hi.value))
+        self.packed_version = None   # parameter version the packed weights correspond to
+        self.packed_train = False
+
+    def tensors(self) -> Dict[str, dict]:
+        """Named activation / gradient views inside the workspace (for parity checks)."""
+        L = lib()
+        out = {}
+        for i in range(L.mi_unet_plan_num_tensors(self.handle)):
+            name = C.create_string_buffer(96)
+            off, dims, cs, co, lay = C.c_int64(), (C.c_int * 4)(), C.c_int(), C.c_int(), C.c_int()
+            check(L.mi_unet_plan_tensor_info(self.handle, i, name, 96, C.byref(off), C.byref(dims), C.byref(cs),
+                                             C.byref(co), C.byref(lay)), "tensor_info")
+            out[name.value.decode()] = dict(offset=off.value, dims=tuple(dims), cstride=cs.value, coff=co.value,
+                                            layout=lay.value)
+        return out
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().mi_unet_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Autograd node for the whole network: forward = one launch sequence, backward = one
+    segmented launch sequence writing a flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model = model
+        ctx.x_requires_grad = bool(ctx.needs_input_grad[1])
+        ctx.plan = model._forward_impl(x, train=True, need_input_grad=ctx.x_requires_grad)
+        return model._last_pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        model, plan = ctx.model, ctx.plan
+        flat_grad, dx = model._backward_impl(plan, dpred, out=None, beta=0.0)
+        grads = tuple(flat_grad[o:o + n].view(shape) for (o, n, shape) in model._flat_layout)
+        return (None, dx if ctx.x_requires_grad else None) + grads
+
+
+class UNet(nn.Module):
+    """U-Net for traffic-matrix prediction, MI355X-native.
+
+    Arguments are the reference's (models/unet2d.py:9-15) plus ``compute_dtype``:
+    ``"bf16"`` (bf16 storage + bf16 MFMA with fp32 accumulation; parameters, gradients and
+    optimiser state stay fp32) or ``"fp32"`` (exact-fp32 MFMA throughout)."""
+
+    def __init__(self, in_channels=1, out_channels=1, features=(32, 64, 128, 256), out_size=None,
+                 compute_dtype=None):
+        super().__init__()
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.features = tuple(int(f) for f in features)
+        self.out_size = tuple(out_size) if out_size is not None else None
+        self.compute_dtype = torch_dtype(compute_dtype if compute_dtype is not None else DEFAULT_COMPUTE_DTYPE)
+
+        # Parameter containers.  They exist so that state_dict keys, shapes, default
+        # initialisation and RNG consumption order equal the reference's; forward() never
+        # calls them.
+        self.downs = nn.ModuleList()
+        self.ups = nn.ModuleList()
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        ch = self.in_channels
+        for f in self.features:
+            self.downs.append(nn.Sequential(nn.Conv2d(ch, f, 3, padding=1), nn.ReLU(inplace=True),
+                                            nn.Conv2d(f, f, 3, padding=1), nn.ReLU(inplace=True)))
+            ch = f
+        fb = self.features[-1]
+        self.bottleneck = nn.Sequential(nn.Conv2d(fb, 2 * fb, 3, padding=1), nn.ReLU(inplace=True),
+                                        nn.Conv2d(2 * fb, 2 * fb, 3, padding=1), nn.ReLU(inplace=True))
+        for f in reversed(self.features):
+            self.ups.append(nn.ConvTranspose2d(2 * f, f, kernel_size=2, stride=2))
+            self.ups.append(nn.Sequential(nn.Conv2d(2 * f, f, 3, padding=1), nn.ReLU(inplace=True),
+                                          nn.Conv2d(f, f, 3, padding=1), nn.ReLU(inplace=True)))
+        self.final_conv = nn.Conv2d(self.features[0], self.out_channels, kernel_size=1)
+
+        self._plans: Dict[Tuple, _Plan] = {}
+        self._flat: Optional[torch.Tensor] = None
+        self._flat_layout: List[Tuple[int, int, torch.Size]] = []
+        self._last_pred: Optional[torch.Tensor] = None
+        self._dp = None               # set by distributed.GradientReducer.attach
+        self.last_plan: Optional[_Plan] = None
+
+    # ------------------------------------------------------------------ parameters
+    def _construction_order(self) -> List[nn.Parameter]:
+        """Parameters in the order the layers are constructed = forward execution order
+        (downs, bottleneck, ups, final_conv); the flat buffer uses this order so that
+        gradients become ready back-to-front during backward."""
+        mods = []
+        for blk in self.downs:
+            mods += [blk[0], blk[2]]
+        mods += [self.bottleneck[0], self.bottleneck[2]]
+        for i in range(0, len(self.ups), 2):
+            mods += [self.ups[i], self.ups[i + 1][0], self.ups[i + 1][2]]
+        mods.append(self.final_conv)
+        out = []
+        for m in mods:
+            out += [m.weight, m.bias]
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        # .to()/.cuda()/.float() replace parameter storage: the flat buffer must be rebuilt
+        self._flat = None
+        self._plans.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def _ensure_flat(self, device: torch.device) -> torch.Tensor:
+        params = self._construction_order()
+        if self._flat is not None and self._flat.device == device:
+            base = self._flat.data_ptr()
+            if all(p.data_ptr() == base + 4 * o for p, (o, _, _) in zip(params, self._flat_layout)):
+                return self._flat
+        for p in params:
+            if p.device != device or p.dtype != torch.float32:
+                raise RuntimeError(f"UNet parameters must be float32 on {device} (found {p.dtype} on {p.device}); "
+                                   "call model.to(device) first")
+        layout, off = [], 0
+        for p in params:
+            layout.append((off, p.numel(), p.shape))
+            off = (off + p.numel() + 63) // 64 * 64
+        flat = torch.zeros(off, device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for p, (o, n, shape) in zip(params, layout):
+                view = flat[o:o + n].view(shape)
+                view.copy_(p.data)
+                p.data = view
+        self._flat, self._flat_layout = flat, layout
+        for plan in self._plans.values():
+            plan.packed_version = None
+        return flat
+
+    def flat_parameters(self) -> torch.Tensor:
+        """The flat fp32 buffer all parameters are views of (built on first use)."""
+        return self._ensure_flat(next(self.parameters()).device)
+
+    def _param_version(self) -> int:
+        return sum(p._version for p in self._construction_order())
+
+    def mark_parameters_changed(self):
+        """Tell the module its parameters were updated through raw pointers (the fused
+        optimiser does this) so packed weights are refreshed on the next forward."""
+        for plan in self._plans.values():
+            plan.packed_version = None
+
+    # ------------------------------------------------------------------ plans
+    def _get_plan(self, x: torch.Tensor, need_input_grad: bool) -> _Plan:
+        B, Cc, H, W = x.shape
+        key = (B, H, W, x.device.index, bool(need_input_grad), self.compute_dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, B, H, W, x.device, need_input_grad)
+            flat_elems = lib().mi_unet_plan_flat_elems(plan.handle)
+            if flat_elems != self._flat.numel():
+                raise RuntimeError("internal error: flat parameter layout disagrees with the plan")
+            self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ forward / backward
+    def _check_input(self, x: torch.Tensor):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError("UNet expects a 4-D (B, C, H, W) tensor")
+        if not x.is_cuda:
+            raise RuntimeError("this UNet runs only on an AMD GPU through its HIP kernels; got a CPU tensor "
+                               "(there is no CPU fallback -- move the model and the input to 'cuda')")
+        if x.shape[1] != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {x.shape[1]}")
+
+    def _forward_impl(self, x: torch.Tensor, train: bool, need_input_grad: bool = False) -> _Plan:
+        self._check_input(x)
+        flat = self._ensure_flat(x.device)
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        plan = self._get_plan(x, need_input_grad)
+        flags = MI_FWD_TRAIN if train else 0
+        version = self._param_version()
+        if plan.packed_version != version or (train and not plan.packed_train):
+            flags |= MI_FWD_REPACK
+        oh, ow = plan.out_hw
+        pred = torch.empty((plan.B, self.out_channels, oh, ow), device=x.device, dtype=torch.float32)
+        check(lib().mi_unet_forward(plan.handle, x.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes,
+                                    pred.data_ptr(), flags, torch.cuda.current_stream().cuda_stream), "unet_forward")
+        if flags & MI_FWD_REPACK:
+            plan.packed_version, plan.packed_train = version, train
+        self._last_pred = pred
+        self.last_plan = plan
+        return plan
+
+    def _backward_impl(self, plan: _Plan, dpred: torch.Tensor, out: Optional[torch.Tensor], beta: float,
+                       alpha: float = 1.0):
+        """Run backward over all segments into ``out`` (a flat fp32 buffer; allocated when
+        None).  With a gradient reducer attached, each finished bucket's all-reduce is
+        started while the remaining segments are still being enqueued."""
+        flat = self._flat
+        dpred = dpred.contiguous()
+        if dpred.dtype != torch.float32:
+            dpred = dpred.float()
+        if out is None:
+            out = torch.zeros_like(flat)
+        dx = None
+        if plan.need_input_grad:
+            dx = torch.empty((plan.B, self.in_channels, plan.H, plan.W), device=flat.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream().cuda_stream
+        L = lib()
+        dp = self._dp
+        if dp is None:
+            check(L.mi_unet_backward(plan.handle, dpred.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes,
+                                     out.data_ptr(), alpha, beta, 0, plan.n_segments,
+                                     dx.data_ptr() if dx is not None else None, stream), "unet_backward")
+        else:
+            alpha = alpha * dp.grad_prescale
+            for (seg_lo, seg_hi, lo, hi) in dp.buckets_for(plan):
+                check(L.mi_unet_backward(plan.handle, dpred.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(),
+                                         plan.ws_bytes, out.data_ptr(), alpha, beta, seg_lo, seg_hi,
+                                         dx.data_ptr() if dx is not None else None, stream), "unet_backward")
+                dp.reduce_async(out[lo:hi])
+            dp.wait_all()
+        return out, dx
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        params = self._construction_order()
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        if needs_graph:
+            self._check_input(x)
+            self._ensure_flat(x.device)      # before autograd records the parameter tensors
+            return _UNetFunction.apply(self, x, *self._construction_order())
+        self._forward_impl(x, train=False)
+        return self._last_pred
+
+    # ------------------------------------------------------------------ introspection (tests, debugging)
+    def workspace_tensor(self, name: str, plan: Optional[_Plan] = None) -> torch.Tensor:
+        """Copy of a named activation ("act.*") or gradient ("grad.*") of the last pass as an
+        fp32 NCHW tensor."""
+        from ..ops import from_nhwc
+        plan = plan or self.last_plan
+        info = plan.tensors()[name]
+        B, H, W, Cc = info["dims"]
+        if info["layout"] == 1:
+            n = B * Cc * H * W
+            return plan.ws[info["offset"]: info["offset"] + 4 * n].view(torch.float32).view(B, Cc, H, W).clone()
+        es = 2 if self.compute_dtype == torch.bfloat16 else 4
+        n = B * H * W * info["cstride"]
+        t = plan.ws[info["offset"]: info["offset"] + es * n].view(self.compute_dtype).view(B, H, W, info["cstride"])
+        return from_nhwc(t, Cc, coff=info["coff"])
+
+
+def build_unet_from_cfg(cfg) -> UNet:
+    """Build the UNet from a config object; same attribute names and defaults as the
+    reference (models/unet2d.py:104-122): ``in_channels`` (required), ``out_channels`` = 1,
+    ``unet_features`` = (32, 64, 128, 256), ``H_out``/``W_out`` -> out_size or None.
+    ``compute_dtype`` ("bf16" | "fp32") is this build's one extra, optional attribute."""
+    features = getattr(cfg, "unet_features", (32, 64, 128, 256))
+    out_size = (cfg.H_out, cfg.W_out) if getattr(cfg, "H_out", None) is not None else None
+    return UNet(in_channels=cfg.in_channels, out_channels=getattr(cfg, "out_channels", 1), features=features,
+                out_size=out_size, compute_dtype=getattr(cfg, "compute_dtype", None))

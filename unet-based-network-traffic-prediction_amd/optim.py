@@ -1,0 +1,76 @@
+"""``FusedAdam``: ``torch.optim.Adam`` semantics (train.py:497: default betas/eps, no weight
+decay, no amsgrad) as one HIP kernel launch over the model's flat parameter buffer."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, model=None):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.grad_scale = grad_scale
+        self._model = model     # optional: told when parameters change behind torch's back
+        self._flat_state = {}
+
+    @staticmethod
+    def _flat_span(params, attr):
+        """(start pointer, end pointer) if the tensors tile one ascending, 256-byte-granular
+        flat fp32 range (the layout UNet gives its parameters and gradients), else None."""
+        ts = [getattr(p, attr) if attr else p for p in params]
+        if any(t is None or t.dtype != torch.float32 or not t.is_contiguous() for t in ts):
+            return None
+        start = ts[0].data_ptr()
+        cur = start
+        for t in ts:
+            if t.data_ptr() != cur:
+                return None
+            cur += (t.numel() + 63) // 64 * 64 * 4
+        return start, cur
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            b1, b2 = group["betas"]
+            pspan = self._flat_span(params, None)
+            gspan = self._flat_span(params, "grad")
+            flat_ok = pspan is not None and gspan is not None and len(params) == len(group["params"])
+            st = self._flat_state.setdefault(gi, {"step": 0})
+            st["step"] += 1
+            if flat_ok:
+                n = (pspan[1] - pspan[0]) // 4
+                base_p = params[0]._base if params[0]._base is not None else params[0]
+                base_g = params[0].grad._base if params[0].grad._base is not None else params[0].grad
+                flat_p = base_p.view(-1)
+                flat_g = base_g.view(-1)
+                po = (pspan[0] - flat_p.data_ptr()) // 4
+                go = (gspan[0] - flat_g.data_ptr()) // 4
+                if "m" not in st or st["m"].numel() != n:
+                    st["m"] = torch.zeros(n, device=flat_p.device, dtype=torch.float32)
+                    st["v"] = torch.zeros(n, device=flat_p.device, dtype=torch.float32)
+                ops.adam_step(flat_p[po:po + n], flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2,
+                              group["eps"], st["step"], self.grad_scale)
+            else:
+                for p in params:
+                    ps = self.state[p]
+                    if "m" not in ps:
+                        ps["m"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        ps["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    g = p.grad.contiguous()
+                    if not p.is_contiguous():
+                        raise RuntimeError("FusedAdam needs contiguous parameters")
+                    ops.adam_step(p, g, ps["m"], ps["v"], group["lr"], b1, b2, group["eps"], st["step"],
+                                  self.grad_scale)
+        if self._model is not None:
+            self._model.mark_parameters_changed()
+        return loss
