@@ -2,9 +2,11 @@
 // shared error/dispatch helpers.  Host code only; the kernels live in igemm_*.hip,
 // wgrad_*.hip and pointwise.hip.
 #include "common.h"
+#include "hconv_impl.h"
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace mi {
 
@@ -22,12 +24,33 @@ int check_hip(hipError_t e, const char* what) {
 
 int launch_igemm_f32(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
+int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
+int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_f32(const WgradArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_bf16(const WgradArgs& a, hipStream_t s, const char** name);
 
+// ---- zero page: a file-scope device array; host code must use its resolved device address
+static __device__ __attribute__((aligned(256))) unsigned int mi_zero_page_storage[64];
+static std::mutex g_zero_mutex;
+static const void* g_zero_ptr[64] = {nullptr};
+const void* zero_page() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_zero_mutex);
+  if (g_zero_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(mi_zero_page_storage)) != hipSuccess) return nullptr;
+    g_zero_ptr[dev] = p;
+  }
+  return g_zero_ptr[dev];
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-int launch_igemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** name) {
+int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** name) {
+  IgemmArgs a = a_in;
+  a.zero = zero_page();
+  MI_REQUIRE(a.zero != nullptr, "igemm: cannot resolve the zero page on this device");
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_BF16, "igemm: bad dtype");
   MI_REQUIRE(a.in && a.w && a.out, "igemm: null pointer");
   MI_REQUIRE(a.M > 0 && a.M < (1 << 30), "igemm: pixel count out of range");
@@ -41,13 +64,32 @@ int launch_igemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** name
   MI_REQUIRE(a.epi == E_PLAIN || a.bias != nullptr, "igemm: bias required by this epilogue");
   MI_REQUIRE(a.epi != E_SHUFFLE_BIAS || (a.shufC % 16 == 0 && a.N == 4 * a.shufC), "igemm: bad shuffle width");
   MI_REQUIRE(a.in_co + a.Cin <= a.in_cs, "igemm: input channel range exceeds the view stride");
+  // 3x3 stride-1 convolutions whose images tile evenly into 256-pixel blocks take the halo-tile
+  // kernel (one LDS halo tile serves all 9 taps); everything else the generic gather kernel.
+  if (a.mode == G_3x3 && a.epi != E_SHUFFLE_BIAS && a.M % 256 == 0 && a.Hi == a.Ho && a.Wi == a.Wo) {
+    const int ck = dtype == MI_BF16 ? 32 : 16;
+    int R, G, bands;
+    if (a.Cin % ck == 0 && hconv_tiling(a.Hi, a.Wi, &R, &G, &bands) && (G == 1 || a.B % G == 0)) {
+      HconvArgs h{};
+      h.in = a.in; h.in_cs = a.in_cs; h.in_co = a.in_co;
+      h.w = a.w; h.Kp = a.Kp; h.Cp = a.Cin;
+      h.N = a.N; h.bias = a.epi == E_PLAIN ? nullptr : a.bias; h.n_real = a.n_real; h.relu = a.epi == E_BIAS_RELU;
+      h.out = a.out; h.out_cs = a.out_cs; h.out_co = a.out_co;
+      h.mask = a.mask; h.mask_cs = a.mask_cs; h.mask_co = a.mask_co;
+      h.W = a.Wi; h.R = R; h.G = G; h.HR = G * (R + 2) * (a.Wi + 2); h.bands = bands;
+      h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
+      return dtype == MI_BF16 ? launch_hconv_bf16(h, s, name) : launch_hconv_f32(h, s, name);
+    }
+  }
   return dtype == MI_BF16 ? launch_igemm_bf16(a, s, name) : launch_igemm_f32(a, s, name);
 }
 
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split) {
   const int PB = dtype == MI_BF16 ? 128 : 64;
   const int64_t tiles = (int64_t)((Na + 63) / 64) * ((K + 63) / 64);
-  int64_t splits = (1024 + tiles - 1) / tiles;
+  // enough workgroups to fill 256 CUs twice over, few enough partials for a cheap combine
+  int64_t splits = (512 + tiles - 1) / tiles;
+  if (splits > 64) splits = 64;
   const int64_t max_splits = (M + PB - 1) / PB;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -58,7 +100,10 @@ int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split) {
   return (int)splits;
 }
 
-int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** name) {
+int launch_wgrad(const WgradArgs& a_in, int dtype, hipStream_t s, const char** name) {
+  WgradArgs a = a_in;
+  a.zero = zero_page();
+  MI_REQUIRE(a.zero != nullptr, "wgrad: cannot resolve the zero page on this device");
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_BF16, "wgrad: bad dtype");
   MI_REQUIRE(a.a && a.b && a.part, "wgrad: null pointer");
   MI_REQUIRE(a.M > 0 && a.M < (1 << 30), "wgrad: pixel count out of range");
@@ -142,11 +187,32 @@ IgemmArgs convt_dgrad_args(const void* dy, int ycs, int yco, const void* wb, voi
 struct WgradLayout {
   int splits, pps;
   size_t part_bytes, sum_bytes;
+  // halo-tile kernel (bf16, evenly tiling images): geometry and slab count
+  bool halo;
+  int R, G, bands, pitch, HR, tiles_per_split, slabs;
 };
 WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
-  WgradLayout l;
-  const int Np = pad16(Cout), K = 9 * concat_cp(Cin, split);
-  l.splits = wgrad_choose_splits(B * H * W, Np, K, dtype, &l.pps);
+  WgradLayout l{};
+  const int Np = pad16(Cout), Cp = concat_cp(Cin, split), K = 9 * Cp;
+  const int M = B * H * W;
+  if (dtype == MI_BF16 && M % 256 == 0 && Cp % 32 == 0 &&
+      hwgrad_tiling(H, W, &l.R, &l.G, &l.bands, &l.pitch, &l.HR) && (l.G == 1 || B % l.G == 0)) {
+    l.halo = true;
+    const int ntiles = M / 256;
+    const int nblk = Np % 64 == 0 ? Np / 64 : (Np + 31) / 32;
+    const int blocks = nblk * (Cp / 32);                                       // (n-block, c-block) workgroups per split
+    int splits = (256 + blocks - 1) / blocks;                                  // about one workgroup per CU
+    if (splits > ntiles) splits = ntiles;
+    if (splits > 64) splits = 64;
+    l.tiles_per_split = (ntiles + splits - 1) / splits;
+    l.splits = (ntiles + l.tiles_per_split - 1) / l.tiles_per_split;
+    l.slabs = l.splits * hwgrad_slabs_per_split(Np);
+    l.part_bytes = (size_t)l.slabs * Np * K * sizeof(float);
+    l.sum_bytes = (size_t)l.slabs * Np * sizeof(float);
+    return l;
+  }
+  l.splits = wgrad_choose_splits(M, Np, K, dtype, &l.pps);
+  l.slabs = l.splits;
   l.part_bytes = (size_t)l.splits * Np * K * sizeof(float);
   l.sum_bytes = (size_t)l.splits * Np * sizeof(float);
   return l;
@@ -161,9 +227,25 @@ WgradLayout convt_wgrad_layout(int B, int H, int W, int Cin, int Cout, int dtype
 }
 int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
                       float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int split,
-                      int Cout, int dtype, hipStream_t s, const char** name) {
+                      int Cout, int dtype, hipStream_t s, const char** name, int phase) {
   const WgradLayout l = conv3x3_wgrad_layout(B, H, W, Cin, split, Cout, dtype);
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "conv3x3_wgrad: workspace too small");
+  if (l.halo) {
+    HwgradArgs h{};
+    h.dy = dy; h.dy_cs = ycs; h.dy_co = yco; h.Na = pad16(Cout);
+    h.x = x; h.x_cs = xcs; h.x_co = xco; h.Cb = concat_cp(Cin, split);
+    h.W = W; h.R = l.R; h.G = l.G; h.pitch = l.pitch; h.HR = l.HR; h.bands = l.bands;
+    h.ntiles = B * H * W / 256; h.tiles_per_split = l.tiles_per_split; h.splits = l.splits;
+    h.part = (float*)ws;
+    h.rowsum = (float*)((char*)ws + l.part_bytes);
+    h.zero = zero_page();
+    MI_REQUIRE(h.zero != nullptr, "conv3x3_wgrad: cannot resolve the zero page on this device");
+    MI_REQUIRE(x && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && xcs % 16 == 0 && xco % 16 == 0 &&
+                   ycs % 16 == 0 && yco % 16 == 0, "conv3x3_wgrad: operands must be 16-byte aligned views");
+    int rc = (phase & 1) ? launch_hwgrad_bf16(h, s, name) : MI_OK;
+    if (rc || !(phase & 2)) return rc;
+    return launch_finalize_conv3(h.part, h.rowsum, l.slabs, h.Na, h.Cb, Cout, Cin, split, dW, db, alpha, beta, s);
+  }
   WgradArgs a{};
   a.a = dy; a.a_cs = ycs; a.a_co = yco; a.Na = pad16(Cout);
   a.b = x; a.b_cs = xcs; a.b_co = xco; a.Cb = concat_cp(Cin, split);
@@ -174,13 +256,13 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
   a.splits = l.splits; a.pix_per_split = l.pps;
   a.M = B * H * W;
   a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
-  int rc = launch_wgrad(a, dtype, s, name);
-  if (rc) return rc;
+  int rc = (phase & 1) ? launch_wgrad(a, dtype, s, name) : MI_OK;
+  if (rc || !(phase & 2)) return rc;
   return launch_finalize_conv3(a.part, a.rowsum, l.splits, a.Na, a.Cb, Cout, Cin, split, dW, db, alpha, beta, s);
 }
 int run_convt_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
                     float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
-                    int dtype, hipStream_t s, const char** name) {
+                    int dtype, hipStream_t s, const char** name, int phase) {
   const WgradLayout l = convt_wgrad_layout(B, H, W, Cin, Cout, dtype);
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "convt2x2_wgrad: workspace too small");
   WgradArgs a{};
@@ -193,8 +275,8 @@ int run_convt_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, in
   a.splits = l.splits; a.pix_per_split = l.pps;
   a.M = B * H * W;
   a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
-  int rc = launch_wgrad(a, dtype, s, name);
-  if (rc) return rc;
+  int rc = (phase & 1) ? launch_wgrad(a, dtype, s, name) : MI_OK;
+  if (rc || !(phase & 2)) return rc;
   return launch_finalize_convt(a.part, a.colsum, l.splits, a.Na, a.Cb, Cin, Cout, dW, db, alpha, beta, s);
 }
 
@@ -256,7 +338,7 @@ int mi_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, i
                      int Cout, int dtype, mi_stream s) {
   MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "conv3x3_wgrad: bad arguments");
   return run_conv3x3_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, split, Cout,
-                           dtype, (hipStream_t)s, nullptr);
+                           dtype, (hipStream_t)s, nullptr, 3);
 }
 
 int mi_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C, int dtype,
@@ -293,7 +375,7 @@ int mi_convt2x2_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
                       int dtype, mi_stream s) {
   MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "convt2x2_wgrad: bad arguments");
   return run_convt_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, Cout, dtype,
-                         (hipStream_t)s, nullptr);
+                         (hipStream_t)s, nullptr, 3);
 }
 
 int mi_conv1x1_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,

@@ -33,6 +33,22 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
   return (uint32_t)(((uint64_t)n * f.mul) >> f.shift);
 }
 
+// Device address of 256 bytes of zeros (a file-scope __device__ array of the library, resolved
+// once per device).  Loader lanes whose element is padding (conv halo, out-of-range pixel,
+// channel tail) read from here instead of branching around the load or zeroing the result
+// afterwards: the address select happens BEFORE the load, so nothing depends on the loaded
+// data until it is written to LDS and every staging load stays in flight across the MFMA
+// phase.  Kernels receive it as the `zero` field of their argument struct.
+const void* zero_page();
+
+// Makes a selected load offset opaque to the optimiser.  Without it the compiler turns
+// "offset = padding ? zero_page : element; load(base + offset)" back into two branches with a
+// load (and a wait) in each, which serialises the staging loads of a stage.
+__device__ __forceinline__ int64_t opaque_offset(int64_t v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 int check_hip(hipError_t e, const char* what);
@@ -62,6 +78,7 @@ struct IgemmArgs {
   int shufC;                             // E_SHUFFLE_BIAS: N = 4*shufC
   int M;
   FastDiv divHW, divW;                   // by Ho*Wo and by Wo
+  const void* zero;                      // zero page (filled in by launch_igemm)
 };
 int launch_igemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
 
@@ -81,7 +98,21 @@ struct WgradArgs {
   int splits, pix_per_split;
   int M;
   FastDiv divHW, divW;
+  const void* zero;                        // zero page (filled in by launch_wgrad)
 };
+// Halo-tile weight gradient (hwgrad_bf16.hip): 3x3 convs on evenly tiling images, bf16 only.
+struct HwgradArgs {
+  const void* dy; int dy_cs, dy_co; int Na;
+  const void* x; int x_cs, x_co; int Cb;
+  int W, R, G, pitch, HR, bands;
+  int ntiles, tiles_per_split, splits;
+  float* part;      // [slabs_per_split*splits][Na][9*Cb]
+  float* rowsum;    // [slabs_per_split*splits][Na] or null
+  const void* zero; // zero page
+};
+bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR);
+int hwgrad_slabs_per_split(int Na);
+int launch_hwgrad_bf16(const HwgradArgs& a, hipStream_t s, const char** name);
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
 int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
 // dW (Cout,Cin,3,3), db from partials laid out [z][Npad][9*Cp] / rowsum [z][Npad]

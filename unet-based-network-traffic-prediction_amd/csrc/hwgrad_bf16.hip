@@ -1,0 +1,237 @@
+// Halo-tile weight-gradient kernel for gfx950 (bf16): dW of the reference's Conv2d(k=3,
+// padding=1) layers (models/unet2d.py:28-31, :38-41, :51-54), i.e. their autograd backward
+// w.r.t. the weights, for images that tile evenly into 256-pixel blocks.
+//
+//   part[s][n][tap*Cb + c] = sum_{p in pixel range s} dy[p][n] * x[p + tap][c]
+//
+// A 512-thread workgroup owns NB (32|64) dy-channels x 32 x-channels x all 9 taps and walks
+// its share of the pixel tiles.  Per tile it stages the dy tile [256 px][NB] and ONE
+// zero-ringed halo tile of x [halo rows][32 ch] in LDS; the 9 taps read their MFMA fragments
+// from that halo tile at constant row offsets, so x is fetched ~1.3x instead of 9x.  The
+// reduction runs over pixels (the slow index of NHWC), so fragments are read transposed with
+// ds_read_b64_tr_b16.  Halo rows are laid out with a pitch that is a multiple of 16 rows:
+// a vertical tap shift then leaves the swizzle bits unchanged and becomes an immediate
+// offset; the three horizontal shifts use three precomputed addresses.
+// Each wave keeps 2 n-tiles x 1 c-tile x 9 taps of accumulators; waves that share an
+// accumulator block split the tile's pixels and write separate partial slabs, which the
+// fixed-order combine pass sums (bitwise repeatable, no atomics).
+#include "wgrad_impl.h"
+#include "hconv_impl.h"
+
+namespace mi {
+
+constexpr int kHwMaxHalo = 640;   // halo rows (pitch-padded) the LDS buffer holds
+
+// dy tile: [256][NB] bf16.  NB = 64 -> 128-byte rows (32-byte column group ^ row bits 1,3);
+// NB = 32 -> 64-byte rows (32-byte column group ^ row bit 3).
+template <int NB> __device__ __forceinline__ int dy_off(int r, int q /*16-byte chunk*/);
+template <> __device__ __forceinline__ int dy_off<64>(int r, int q) { return tile_off<__bf16>(r, q); }
+template <> __device__ __forceinline__ int dy_off<32>(int r, int q) {
+  return r * 64 + (((((q >> 1) ^ ((r >> 3) & 1)) << 1) | (q & 1)) << 4);
+}
+// x halo tile: [rows][32] bf16 = 64-byte rows, same rule as dy_off<32>.
+__device__ __forceinline__ int xh_off(int r, int q) { return dy_off<32>(r, q); }
+
+__device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+  union { s16x4_t s[2]; bf16x8_t v; } u;
+  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+  return u.v;
+}
+
+template <int NB>
+__global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
+  typedef __bf16 T;
+  constexpr int COMBOS = (NB / 32) * 2;        // (n-pair, c-tile) accumulator blocks
+  constexpr int PG = 8 / COMBOS;               // waves sharing a block split the pixels PG ways
+  constexpr int KSP = 8 / PG;                  // 32-pixel k-steps per wave per tile
+  constexpr int DY_BYTES = 256 * NB * 2;
+  constexpr int X_BYTES = kHwMaxHalo * 64;
+  constexpr int STAGE = DY_BYTES + X_BYTES;
+  constexpr int DY_CPR = NB / 8;               // 16-byte chunks per dy row
+  constexpr int DY_IT = 256 * DY_CPR / 512;
+  constexpr int X_IT = kHwMaxHalo * 4 / 512;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n0 = blockIdx.x * NB, c0 = blockIdx.y * 32, z = blockIdx.z;
+  const T* __restrict__ pdy = (const T*)a.dy;
+  const T* __restrict__ px = (const T*)a.x;
+  const int grp_rows = (a.R + 2) * a.pitch;
+
+  // ---- loader state
+  int xrel[X_IT], xlds[X_IT];      // x halo: pixel offset rel. to tile start; LDS byte offset | kind, or -1
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int id = t + 512 * i, hr = id >> 2, ch = id & 3;
+    xrel[i] = 0; xlds[i] = -1;
+    if (hr < a.HR) {
+      const int g = hr / grp_rows, rem = hr - g * grp_rows;
+      const int hy = rem / a.pitch, hx = rem - hy * a.pitch;
+      if (hx <= a.W + 1) {
+        xrel[i] = g * a.R * a.W + (hy - 1) * a.W + (hx - 1);
+        const int kind = (hx == 0 || hx == a.W + 1) ? 1 : (hy == 0 ? 2 : (hy == a.R + 1 ? 3 : 0));
+        xlds[i] = xh_off(hr, ch) | kind;
+      }
+    }
+  }
+  const int xchq = (t & 3) * 8;
+  // element offsets of the zero page relative to each operand's base pointer
+  const int64_t zoff_dy = ((intptr_t)a.zero - (intptr_t)a.dy) / 2, zoff_x = ((intptr_t)a.zero - (intptr_t)a.x) / 2;
+  const int dy_ch = t % DY_CPR, dy_row0 = t / DY_CPR;
+  const bool dy_ok = n0 + dy_ch * 8 < a.Na;
+
+  u32x4_t rdy[DY_IT], rx[X_IT];
+  auto load_tile = [&](int tile) {
+    const int64_t base = (int64_t)tile * 256;
+    const int band = tile % a.bands;
+    const bool top0 = band == 0, bot0 = band == a.bands - 1;
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) {
+      const int row = dy_row0 + i * (512 / DY_CPR);
+      // integer select of the offset from one base pointer (a select between two pointers makes
+      // the optimiser split the load into branches)
+      const int64_t off = dy_ok ? (base + row) * a.dy_cs + a.dy_co + n0 + dy_ch * 8 : zoff_dy;
+      rdy[i] = *(const u32x4_t*)(pdy + opaque_offset(off));
+    }
+    const int coff = a.x_co + c0 + xchq;
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int kind = xlds[i] & 3;
+      const bool zero = xlds[i] < 0 || kind == 1 || (kind == 2 && top0) || (kind == 3 && bot0);
+      const int64_t off = zero ? zoff_x : (base + xrel[i]) * a.x_cs + coff;
+      rx[i] = *(const u32x4_t*)(px + opaque_offset(off));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* D = smem + buf * STAGE;
+    char* X = D + DY_BYTES;
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) *(u32x4_t*)(D + dy_off<NB>(dy_row0 + i * (512 / DY_CPR), dy_ch)) = rdy[i];
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i)
+      if (xlds[i] >= 0) *(u32x4_t*)(X + (xlds[i] & ~15)) = rx[i];
+  };
+
+  // ---- wave role and fragment addresses
+  const int combo = wave % COMBOS, pg = wave / COMBOS;
+  const int ct = combo & 1, np = combo >> 1;
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  int a_addr[KSP][2][2];      // dy fragment addresses [k-step][n-tile][row half]
+  int b_addr[KSP][2][3];      // x fragment addresses [k-step][row half][tx]
+#pragma unroll
+  for (int k = 0; k < KSP; ++k) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = (pg * KSP + k) * 32 + 8 * g + q + 4 * h;      // pixel inside the tile
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = np * 32 + nt * 16 + 4 * pp;                // channel inside the dy tile
+        a_addr[k][nt][h] = dy_off<NB>(pl, col >> 3) + (col & 7) * 2;
+      }
+      const int gi = pl / (a.R * a.W), rem = pl - gi * (a.R * a.W);
+      const int y = rem / a.W, xx = rem - y * a.W;
+      const int hrow = gi * grp_rows + y * a.pitch + xx;            // halo row of tap (0,0)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int col = ct * 16 + 4 * pp;
+        b_addr[k][h][tx] = DY_BYTES + xh_off(hrow + tx, col >> 3) + (col & 7) * 2;
+      }
+    }
+  }
+  const int ty_bytes = a.pitch * 64;
+
+  f32x4_t acc[9][2], accr[2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) { acc[tp][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[tp][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  accr[0] = accr[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_rows = a.rowsum != nullptr && blockIdx.y == 0 && ct == 0;
+  const bf16x8_t ones = ones_frag(T());
+
+  auto compute = [&](int buf) {
+    const char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < KSP; ++k) {
+      const bf16x8_t a0 = tr_pair(S + a_addr[k][0][0], S + a_addr[k][0][1]);
+      const bf16x8_t a1 = tr_pair(S + a_addr[k][1][0], S + a_addr[k][1][1]);
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int ty = tp / 3, tx = tp % 3;
+        const char* Sy = S + ty * ty_bytes;
+        const bf16x8_t b = tr_pair(Sy + b_addr[k][0][tx], Sy + b_addr[k][1][tx]);
+        acc[tp][0] = mma_px(a0, b, acc[tp][0]);
+        acc[tp][1] = mma_px(a1, b, acc[tp][1]);
+      }
+      if (do_rows) {
+        accr[0] = mma_px(a0, ones, accr[0]);
+        accr[1] = mma_px(a1, ones, accr[1]);
+      }
+    }
+  };
+
+  const int t_begin = z * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    store_tile(0);
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int s = tile - t_begin;
+      const bool more = tile + 1 < t_end;
+      if (more) load_tile(tile + 1);
+      compute(s & 1);
+      if (more) store_tile((s + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- write this wave's partial slab: D row = n (4*(lane>>4)+j), col = c (lane & 15)
+  const int K = 9 * a.Cb;
+  const int slab = z * PG + pg;
+  float* part = a.part + (int64_t)slab * a.Na * K;
+  const int c = c0 + ct * 16 + i16;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + np * 32 + nt * 16 + 4 * g + j;
+      if (n < a.Na && c < a.Cb) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) part[(int64_t)n * K + tp * a.Cb + c] = acc[tp][nt][j];
+      }
+    }
+  if (do_rows && i16 == 0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + np * 32 + nt * 16 + 4 * g + j;
+        if (n < a.Na) a.rowsum[(int64_t)slab * a.Na + n] = accr[nt][j];
+      }
+  }
+}
+
+// Tiling with a 16-row-aligned halo pitch; false when the kernel does not apply.
+bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR) {
+  if (!hconv_tiling(H, W, R, G, bands)) return false;
+  *pitch = (W + 2 + 15) / 16 * 16;
+  *HR = (*G) * (*R + 2) * (*pitch);
+  return *HR <= kHwMaxHalo;
+}
+int hwgrad_slabs_per_split(int Na) { return Na % 64 == 0 ? 2 : 4; }
+
+int launch_hwgrad_bf16(const HwgradArgs& a, hipStream_t s, const char** name) {
+  if (a.Na % 64 == 0) {
+    dim3 grid(a.Na / 64, a.Cb / 32, a.splits);
+    if (name) *name = "hwgrad_64x32x9";
+    hipLaunchKernelGGL((hwgrad_kernel<64>), grid, dim3(512), 0, s, a);
+  } else {
+    dim3 grid((a.Na + 31) / 32, a.Cb / 32, a.splits);
+    if (name) *name = "hwgrad_32x32x9";
+    hipLaunchKernelGGL((hwgrad_kernel<32>), grid, dim3(512), 0, s, a);
+  }
+  return check_hip(hipGetLastError(), "hwgrad launch");
+}
+
+}  // namespace mi

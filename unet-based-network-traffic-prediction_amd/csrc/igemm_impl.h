@@ -22,6 +22,9 @@ namespace mi {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// staging registers are native vectors: an aggregate (HIP's uint4 struct) copied out of global
+// memory becomes a memcpy into a private array and drags the array into scratch
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   const T* __restrict__ in = (const T*)a.in;
   const T* __restrict__ wp = (const T*)a.w;
   const int HW = a.Ho * a.Wo;
+  const int64_t zoff_in = ((intptr_t)a.zero - (intptr_t)a.in) / (int64_t)sizeof(T);  // zero page, in elements from `in`
 
   // Per-row gather state of this thread's A_IT pixel rows.
   int64_t base[A_IT];
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   const int cpt = a.Cin / EPC;
   int tap = sub / cpt, cc = sub % cpt;
 
-  uint4 ra[A_IT], rb[B_IT];
+  u32x4_t ra[A_IT], rb[B_IT];
   auto load_stage = [&](int kstage) {
     int64_t toff = 0;
     int dy = 0, dx = 0;
@@ -125,15 +129,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         ok = ok && ((unsigned)(yy[i] + dy) < (unsigned)a.Hi) && ((unsigned)(xx[i] + dx) < (unsigned)a.Wi);
       else
         ok = ok && (base[i] >= 0);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(in + base[i] + toff);
-      ra[i] = v;
+      // padding lanes read the zero page: address select before the load, no use of the data
+      // until the LDS store, so all staging loads stay in flight across the MFMA phase
+      // (integer select of the OFFSET from one base pointer: a select between two pointers
+      // makes the optimiser split the load into branches again)
+      const int64_t off = ok ? base[i] + toff : zoff_in;
+      ra[i] = *(const u32x4_t*)(in + opaque_offset(off));
     }
     const int64_t kel = (int64_t)(kstage * CPS + sub) * EPC;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = row0 + i * RPP;
-      if (row < BN) rb[i] = *(const uint4*)(wp + (int64_t)(n0 + row) * a.Kp + kel);
+      rb[i] = *(const u32x4_t*)(wp + (int64_t)(n0 + (row < BN ? row : 0)) * a.Kp + kel);
     }
   };
   auto advance = [&]() {
@@ -150,12 +157,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = row0 + i * RPP;
-      *(uint4*)(A + s * (BM * 64) + row * 64 + ((c ^ (((row >> 2) & 1) << 1)) << 4)) = ra[i];
+      *(u32x4_t*)(A + s * (BM * 64) + row * 64 + ((c ^ (((row >> 2) & 1) << 1)) << 4)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int row = row0 + i * RPP;
-      if (row < BN) *(uint4*)(Bt + s * (BN * 64) + row * 64 + ((c ^ (((row >> 2) & 1) << 1)) << 4)) = rb[i];
+      if (row < BN) *(u32x4_t*)(Bt + s * (BN * 64) + row * 64 + ((c ^ (((row >> 2) & 1) << 1)) << 4)) = rb[i];
     }
   };
 
@@ -203,6 +210,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   // Epilogue: lane holds channels n..n+3 (n = tile*16 + 4*(lane>>4)) of pixel (lane&15).
   T* __restrict__ out = (T*)a.out;
   const T* __restrict__ mask = (const T*)a.mask;
+  // bias of this lane's 4 channels per channel tile, read once with clamped unconditional loads
+  f32x4_t biasv[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + (wn * TN + i) * 16 + 4 * ch;
+    const int c0 = a.epi == E_SHUFFLE_BIAS ? n % a.shufC : n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float b = 0.f;
+      if (a.epi != E_PLAIN) {
+        b = a.bias[c0 + q < a.n_real ? c0 + q : 0];
+        if (c0 + q >= a.n_real) b = 0.f;
+      }
+      biasv[i][q] = b;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int p = p0 + (wm * TM + j) * 16 + r16;
@@ -222,13 +245,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
       int64_t o;
       if (a.epi == E_SHUFFLE_BIAS) {
         const int g = n / a.shufC, co = n - g * a.shufC;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += (co + q < a.n_real) ? a.bias[co + q] : 0.f;
+        v += biasv[i];
         o = (opix + (int64_t)(g >> 1) * (2 * a.Wo) + (g & 1)) * a.out_cs + a.out_co + co;
       } else {
         if (a.epi != E_PLAIN) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += (n + q < a.n_real) ? a.bias[n + q] : 0.f;
+          v += biasv[i];
           if (a.epi == E_BIAS_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;

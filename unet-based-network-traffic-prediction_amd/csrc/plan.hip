@@ -29,9 +29,9 @@ IgemmArgs conv3x3_dgrad_args(const void*, int, int, const void*, void*, int, int
 IgemmArgs convt_fwd_args(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, int);
 IgemmArgs convt_dgrad_args(const void*, int, int, const void*, void*, int, int, const void*, int, int, int, int, int, int, int);
 int run_conv3x3_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
-                      int, int, int, int, int, hipStream_t, const char**);
+                      int, int, int, int, int, hipStream_t, const char**, int);
 int run_convt_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
-                    int, int, int, int, hipStream_t, const char**);
+                    int, int, int, int, hipStream_t, const char**, int);
 
 enum LayerKind { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2 };
 struct Layer {
@@ -183,14 +183,18 @@ int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, in
 int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float alpha, float beta, int B, int H, int W,
                   const char* label) {
   const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
-  const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P) + 4.0 * l.cout * l.cin * 9;
-  Scope sc(r.P, r.s, label, fl, by);
-  const char* k = nullptr;
-  int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
-                             r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout, r.P->d.dtype,
-                             r.s, &k);
-  sc.kernel(k);
-  return rc;
+  const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
+  for (int phase = 1; phase <= 2; ++phase) {
+    Scope sc(r.P, r.s, phase == 1 ? label : (std::string(label) + ".reduce").c_str(), phase == 1 ? fl : 0.0,
+             phase == 1 ? by : 4.0 * l.cout * l.cin * 9);
+    const char* k = phase == 1 ? nullptr : "finalize_conv3";
+    int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
+                               r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout,
+                               r.P->d.dtype, r.s, phase == 1 ? &k : nullptr, phase);
+    sc.kernel(k);
+    if (rc) return rc;
+  }
+  return MI_OK;
 }
 
 void bil_strides_nhwc(const Tensor& t, int64_t s[4]) {
@@ -632,13 +636,16 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
       View gprev = j == 0 ? r.view("g.b2") : r.view("g.u2." + std::to_string(j - 1));
       {
         const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
-        Scope sc(P, r.s, (up.prefix + ".wgrad").c_str(), fl, (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P));
-        const char* k = nullptr;
-        int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
-                                 alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
-                                 r.s, &k);
-        sc.kernel(k);
-        RUN(rc);
+        for (int phase = 1; phase <= 2; ++phase) {
+          Scope sc(P, r.s, (up.prefix + (phase == 1 ? ".wgrad" : ".wgrad.reduce")).c_str(), phase == 1 ? fl : 0.0,
+                   phase == 1 ? (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P) : 16.0 * up.cin * up.cout);
+          const char* k = phase == 1 ? nullptr : "finalize_convt";
+          int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
+                                   alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
+                                   r.s, phase == 1 ? &k : nullptr, phase);
+          sc.kernel(k);
+          RUN(rc);
+        }
       }
       {
         const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;

@@ -14,6 +14,11 @@ static inline int grid_for(int64_t work_items, int block = 256, int max_blocks =
   return (int)g;
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
 
@@ -383,13 +388,77 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     if (pr < npairs) part[(int64_t)blockIdx.x * npairs + pr] = accp[k];
   }
 }
-__global__ void head_finalize_kernel(const float* __restrict__ part, int nblocks, int Cin, int Cp, int Cout,
-                                     float* __restrict__ dW, float* __restrict__ db, float alpha, float beta) {
+// Head backward for one or two output channels (the usual 1-step prediction): every thread
+// keeps the dW row(s) of its own pixels in registers across a grid-stride loop; one
+// wave-shuffle + LDS reduction per workgroup at the end.  Partials: [block][Cout*Cp + Cout].
+template <typename T, int COUT, int CP>
+__global__ __launch_bounds__(256) void head_bwd_small_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                              const float* __restrict__ w, const float* __restrict__ dpred,
+                                                              T* __restrict__ dx, int dcs, int dco, float* __restrict__ part,
+                                                              int64_t npix, int HW, int Cin, int relu_mask) {
+  __shared__ float sw[COUT * CP];
+  __shared__ float red[4][COUT * CP + COUT];
+  for (int i = threadIdx.x; i < COUT * CP; i += 256) {
+    const int co = i / CP, c = i % CP;
+    sw[i] = c < Cin ? w[co * Cin + c] : 0.f;
+  }
+  __syncthreads();
+  float acc[COUT][CP], accb[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    accb[co] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[co][c] = 0.f;
+  }
+  for (int64_t p = blockIdx.x * 256ll + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int64_t b = p / HW, r = p % HW;
+    float g[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) { g[co] = dpred[(b * COUT + co) * HW + r]; accb[co] += g[co]; }
+#pragma unroll
+    for (int c = 0; c < CP; c += 4) {
+      const f32x4_t xv = load4f(x + p * xcs + xco + c);
+      f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          d[q] = fmaf(g[co], sw[co * CP + c + q], d[q]);
+          acc[co][c + q] = fmaf(g[co], xv[q], acc[co][c + q]);
+        }
+      if (relu_mask) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = xv[q] > 0.f ? d[q] : 0.f;
+      }
+      store4f(dx + p * dcs + dco + c, d);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float v = wave_sum(acc[co][c]);
+      if (lane == 0) red[wave][co * CP + c] = v;
+    }
+    const float vb = wave_sum(accb[co]);
+    if (lane == 0) red[wave][COUT * CP + co] = vb;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < COUT * CP + COUT; i += 256)
+    part[(int64_t)blockIdx.x * (COUT * CP + COUT) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+__global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restrict__ part, int nblocks, int Cin, int Cp,
+                                                            int Cout, float* __restrict__ dW, float* __restrict__ db,
+                                                            float alpha, float beta) {
+  // one wave per (co, c) pair: strided partial sums, then a shuffle reduction (fixed order)
   const int npairs = Cout * Cp + Cout;
-  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pr >= npairs) return;
+  const int pr = blockIdx.x;
   float s = 0.f;
-  for (int i = 0; i < nblocks; ++i) s += part[(int64_t)i * npairs + pr];
+  for (int i = threadIdx.x; i < nblocks; i += 64) s += part[(int64_t)i * npairs + pr];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (threadIdx.x != 0) return;
   if (pr < Cout * Cp) {
     const int co = pr / Cp, c = pr % Cp;
     if (c < Cin) {
@@ -412,6 +481,26 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
   const int64_t npix = (int64_t)B * H * W;
   const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
   const int nblocks = (int)(ntiles < kHeadBlocks ? ntiles : kHeadBlocks);
+  if (Cout <= 2 && (Cp == 32 || Cp == 16)) {
+    int nb = (int)((npix + 255) / 256);
+    if (nb > kHeadBlocks) nb = kHeadBlocks;
+#define HEAD_SMALL(TT, CO, CPV)                                                                                   \
+    hipLaunchKernelGGL((head_bwd_small_kernel<TT, CO, CPV>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred, \
+                       (TT*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, relu_mask)
+    if (dtype == MI_BF16) {
+      if (Cout == 1 && Cp == 32) HEAD_SMALL(__bf16, 1, 32); else if (Cout == 1) HEAD_SMALL(__bf16, 1, 16);
+      else if (Cp == 32) HEAD_SMALL(__bf16, 2, 32); else HEAD_SMALL(__bf16, 2, 16);
+    } else {
+      if (Cout == 1 && Cp == 32) HEAD_SMALL(float, 1, 32); else if (Cout == 1) HEAD_SMALL(float, 1, 16);
+      else if (Cp == 32) HEAD_SMALL(float, 2, 32); else HEAD_SMALL(float, 2, 16);
+    }
+#undef HEAD_SMALL
+    int rc2 = check_hip(hipGetLastError(), "head_bwd_small");
+    if (rc2) return rc2;
+    const int np2 = Cout * Cp + Cout;
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(np2), dim3(64), 0, s, (const float*)ws, nb, Cin, Cp, Cout, dW, db, alpha, beta);
+    return check_hip(hipGetLastError(), "head_finalize");
+  }
   const size_t shm = (size_t)(Cout * Cp + kHeadTile * (Cp + 1) + kHeadTile * Cout) * sizeof(float);
   if (dtype == MI_BF16)
     hipLaunchKernelGGL(head_bwd_kernel<__bf16>, dim3(nblocks), dim3(256), shm, s, (const __bf16*)x, xcs, xco, w, dpred, (__bf16*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, Cp, Cout, relu_mask);
@@ -420,17 +509,12 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
   int rc = check_hip(hipGetLastError(), "head_bwd");
   if (rc) return rc;
   const int npairs = Cout * Cp + Cout;
-  hipLaunchKernelGGL(head_finalize_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, (const float*)ws, nblocks, Cin, Cp, Cout, dW, db, alpha, beta);
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(npairs), dim3(64), 0, s, (const float*)ws, nblocks, Cin, Cp, Cout, dW, db, alpha, beta);
   return check_hip(hipGetLastError(), "head_finalize");
 }
 
 // ------------------------------------------------------------------------------------------
 // MSE: per-workgroup partial sums (wave shuffle -> LDS), then one small fixed-order pass.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
 __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                            int64_t n, float* __restrict__ dpred, float coef,
                                                            const float* __restrict__ gdev, float* __restrict__ part) {
@@ -624,66 +708,117 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 
 // ------------------------------------------------------------------------------------------
 // Fixed-order combination of weight-gradient partials into the reference's parameter layout.
-__global__ void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum, int splits,
-                                      int Npad, int Cp, int Cout, int Cin, int split, float* __restrict__ dW,
-                                      float* __restrict__ db, float alpha, float beta) {
-  // thread per (co, k) with k fastest: coalesced partial reads, strided (x9) writes
+// A 256-thread workgroup handles 64 consecutive partial columns; the split range is cut in 4
+// interleaved groups (one per wave) and each thread keeps 4 independent sums, so 16 loads per
+// output are in flight.  The combination order is fixed, hence bitwise repeatable.
+__device__ __forceinline__ float sum_splits4(const float* __restrict__ p, int64_t stride, int z0, int splits) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int z = z0;
+  for (; z + 12 < splits; z += 16) {
+    a0 += p[(int64_t)z * stride];
+    a1 += p[(int64_t)(z + 4) * stride];
+    a2 += p[(int64_t)(z + 8) * stride];
+    a3 += p[(int64_t)(z + 12) * stride];
+  }
+  for (; z < splits; z += 4) a0 += p[(int64_t)z * stride];
+  return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ float combine4(float v, float* sh) {
+  // sh: [4][64]; returns the total in the threads of wave 0
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  const int o = threadIdx.x & 63;
+  return (sh[o] + sh[64 + o]) + (sh[128 + o] + sh[192 + o]);
+}
+__global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum,
+                                                              int splits, int Npad, int Cp, int Cout, int Cin, int split,
+                                                              float* __restrict__ dW, float* __restrict__ db, float alpha,
+                                                              float beta) {
+  __shared__ float sh[256];
   const int K = 9 * Cp;
   const int split_pad = (split + 15) / 16 * 16;
   const int64_t total = (int64_t)Cout * K + Cout;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < (int64_t)Cout * K) {
-      const int co = (int)(i / K), k = (int)(i % K);
-      const int tap = k / Cp, pos = k % Cp;
-      const int ci = unpos(pos, Cin, split, split_pad);
-      if (ci < 0) continue;
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += part[((int64_t)z * Npad + co) * K + k];
-      float* o = dW + ((int64_t)co * Cin + ci) * 9 + tap;
-      *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
-    } else if (db != nullptr) {
-      const int co = (int)(i - (int64_t)Cout * K);
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += rowsum[(int64_t)z * Npad + co];
-      db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+  const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + o;
+    float v = 0.f;
+    int co = 0, k = 0;
+    const bool is_w = i < (int64_t)Cout * K, live = i < total;
+    if (live) {
+      if (is_w) {
+        co = (int)(i / K); k = (int)(i % K);
+        v = sum_splits4(part + (int64_t)co * K + k, (int64_t)Npad * K, zg, splits);
+      } else {
+        co = (int)(i - (int64_t)Cout * K);
+        if (rowsum) v = sum_splits4(rowsum + co, Npad, zg, splits);
+      }
     }
+    const float s = combine4(v, sh);
+    if (zg == 0 && live) {
+      if (is_w) {
+        const int tap = k / Cp, pos = k % Cp;
+        const int ci = unpos(pos, Cin, split, split_pad);
+        if (ci >= 0) {
+          float* out = dW + ((int64_t)co * Cin + ci) * 9 + tap;
+          *out = alpha * s + (beta != 0.f ? beta * *out : 0.f);
+        }
+      } else if (db != nullptr) {
+        db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+      }
+    }
+    __syncthreads();
   }
 }
-__global__ void finalize_convt_kernel(const float* __restrict__ part, const float* __restrict__ colsum, int splits,
-                                      int Cp_in, int Npad, int Cin, int Cout, float* __restrict__ dW,
-                                      float* __restrict__ db, float alpha, float beta) {
+__global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __restrict__ part, const float* __restrict__ colsum,
+                                                              int splits, int Cp_in, int Npad, int Cin, int Cout,
+                                                              float* __restrict__ dW, float* __restrict__ db, float alpha,
+                                                              float beta) {
+  __shared__ float sh[256];
   const int K = 4 * Npad;
   const int64_t total = (int64_t)Cin * K + Cout;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < (int64_t)Cin * K) {
-      const int ci = (int)(i / K), k = (int)(i % K);
-      const int g = k / Npad, co = k % Npad;
-      if (co >= Cout) continue;
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z) s += part[((int64_t)z * Cp_in + ci) * K + k];
-      float* o = dW + ((int64_t)ci * Cout + co) * 4 + g;
-      *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
-    } else if (db != nullptr) {
-      const int co = (int)(i - (int64_t)Cin * K);
-      float s = 0.f;
-      for (int z = 0; z < splits; ++z)
-        for (int g = 0; g < 4; ++g) s += colsum[(int64_t)z * K + g * Npad + co];
-      db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+  const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + o;
+    float v = 0.f;
+    int ci = 0, k = 0;
+    const bool is_w = i < (int64_t)Cin * K, live = i < total;
+    if (live) {
+      if (is_w) {
+        ci = (int)(i / K); k = (int)(i % K);
+        v = sum_splits4(part + (int64_t)ci * K + k, (int64_t)Cp_in * K, zg, splits);
+      } else if (colsum) {
+        const int co = (int)(i - (int64_t)Cin * K);
+        for (int g = 0; g < 4; ++g) v += sum_splits4(colsum + g * Npad + co, K, zg, splits);
+      }
     }
+    const float s = combine4(v, sh);
+    if (zg == 0 && live) {
+      if (is_w) {
+        const int g = k / Npad, co = k % Npad;
+        if (co < Cout) {
+          float* out = dW + ((int64_t)ci * Cout + co) * 4 + g;
+          *out = alpha * s + (beta != 0.f ? beta * *out : 0.f);
+        }
+      } else if (db != nullptr) {
+        const int co = (int)(i - (int64_t)Cin * K);
+        db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+      }
+    }
+    __syncthreads();
   }
 }
 int launch_finalize_conv3(const float* part, const float* rowsum, int splits, int Npad, int Cp, int Cout, int Cin,
                           int split, float* dW, float* db, float alpha, float beta, hipStream_t s) {
   const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
-  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total)), dim3(256), 0, s, part, rowsum, splits, Npad, Cp, Cout,
-                     Cin, split, dW, db, alpha, beta);
+  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, s, part, rowsum, splits, Npad,
+                     Cp, Cout, Cin, split, dW, db, alpha, beta);
   return check_hip(hipGetLastError(), "finalize_conv3");
 }
 int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin, int Cout,
                           float* dW, float* db, float alpha, float beta, hipStream_t s) {
   const int64_t total = (int64_t)Cin * 4 * Npad + Cout;
-  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total)), dim3(256), 0, s, part, colsum, splits, Cp_in, Npad,
-                     Cin, Cout, dW, db, alpha, beta);
+  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, s, part, colsum, splits, Cp_in,
+                     Npad, Cin, Cout, dW, db, alpha, beta);
   return check_hip(hipGetLastError(), "finalize_convt");
 }
 

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const T* __restrict__ pa = (const T*)a.a;
   const T* __restrict__ pb = (const T*)a.b;
   const int HW = a.Ho * a.Wo;
+  // zero page as element offsets from each operand's base (integer offset select, one base pointer)
+  const int64_t zoff_a = ((intptr_t)a.zero - (intptr_t)a.a) / (int64_t)sizeof(T);
+  const int64_t zoff_b = ((intptr_t)a.zero - (intptr_t)a.b) / (int64_t)sizeof(T);
   const int pbeg = z * a.pix_per_split;
   const int pend = min(a.M, pbeg + a.pix_per_split);
 
@@ -117,33 +120,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
   toff += a.b_co + bc;
 
-  uint4 ra[IT], rb[IT];
+  u32x4_t ra[IT], rb[IT];
   auto load_stage = [&](int pstage) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
+      // Loads are unconditional; padding elements read the zero page (address select before the
+      // load), so no instruction touches the data until the LDS store after the MFMA phase.
       const int p = pstage + row0 + i * RPP;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-      if (p < pend) {
-        if (a_ok) va = *(const uint4*)(pa + (int64_t)p * a.a_cs + a.a_co + an);
-        if (b_ok) {
-          if (MODE == G_1x1) {
-            vb = *(const uint4*)(pb + (int64_t)p * a.b_cs + toff);
-          } else {
-            const uint32_t b = fdiv((uint32_t)p, a.divHW);
-            const uint32_t r = (uint32_t)p - b * (uint32_t)HW;
-            const uint32_t y = fdiv(r, a.divW);
-            const uint32_t x = r - y * (uint32_t)a.Wo;
-            if (MODE == G_3x3) {
-              if ((unsigned)((int)y + dy) < (unsigned)a.Hb && (unsigned)((int)x + dx) < (unsigned)a.Wb)
-                vb = *(const uint4*)(pb + (int64_t)p * a.b_cs + toff);
-            } else {
-              vb = *(const uint4*)(pb + ((int64_t)(b * a.Hb + 2 * y) * a.Wb + 2 * x) * a.b_cs + toff);
-            }
-          }
-        }
+      const bool pv = p < pend;
+      const bool av = pv && a_ok;
+      bool bv = pv && b_ok;
+      int64_t boff = (int64_t)p * a.b_cs;
+      if (MODE != G_1x1) {
+        const uint32_t pc = pv ? (uint32_t)p : 0u;
+        const uint32_t b = fdiv(pc, a.divHW);
+        const uint32_t r = pc - b * (uint32_t)HW;
+        const uint32_t y = fdiv(r, a.divW);
+        const uint32_t x = r - y * (uint32_t)a.Wo;
+        if (MODE == G_3x3)
+          bv = bv && (unsigned)((int)y + dy) < (unsigned)a.Hb && (unsigned)((int)x + dx) < (unsigned)a.Wb;
+        else
+          boff = ((int64_t)(b * a.Hb + 2 * y) * a.Wb + 2 * x) * a.b_cs;
       }
-      ra[i] = va;
-      rb[i] = vb;
+      const int64_t oa = av ? (int64_t)p * a.a_cs + a.a_co + an : zoff_a;
+      const int64_t ob = bv ? boff + toff : zoff_b;
+      ra[i] = *(const u32x4_t*)(pa + opaque_offset(oa));
+      rb[i] = *(const u32x4_t*)(pb + opaque_offset(ob));
     }
   };
   auto store_stage = [&](int buf) {
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int row = row0 + i * RPP;
-      *(uint4*)(At + tile_off<T>(row, cch)) = ra[i];
-      *(uint4*)(Bt + tile_off<T>(row, cch)) = rb[i];
+      *(u32x4_t*)(At + tile_off<T>(row, cch)) = ra[i];
+      *(u32x4_t*)(Bt + tile_off<T>(row, cch)) = rb[i];
     }
   };
 

@@ -31,6 +31,12 @@ class FusedAdam(torch.optim.Optimizer):
             cur += (t.numel() + 63) // 64 * 64 * 4
         return start, cur
 
+    @staticmethod
+    def _storage_as_flat(t: torch.Tensor) -> torch.Tensor:
+        """fp32 1-D tensor over the whole storage ``t`` lives in (the flat buffer it is a view of)."""
+        st = t.untyped_storage()
+        return torch.empty(0, dtype=torch.float32, device=t.device).set_(st, 0, (st.nbytes() // 4,))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -41,6 +47,9 @@ class FusedAdam(torch.optim.Optimizer):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
+            # model.parameters() yields state_dict order (ups before bottleneck); the flat
+            # buffer is laid out in construction order, so walk the tensors by address
+            params.sort(key=lambda p: p.data_ptr())
             b1, b2 = group["betas"]
             pspan = self._flat_span(params, None)
             gspan = self._flat_span(params, "grad")
@@ -49,10 +58,8 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] += 1
             if flat_ok:
                 n = (pspan[1] - pspan[0]) // 4
-                base_p = params[0]._base if params[0]._base is not None else params[0]
-                base_g = params[0].grad._base if params[0].grad._base is not None else params[0].grad
-                flat_p = base_p.view(-1)
-                flat_g = base_g.view(-1)
+                flat_p = self._storage_as_flat(params[0])
+                flat_g = self._storage_as_flat(params[0].grad)
                 po = (pspan[0] - flat_p.data_ptr()) // 4
                 go = (gspan[0] - flat_g.data_ptr()) // 4
                 if "m" not in st or st["m"].numel() != n:
