@@ -41,12 +41,15 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--batch", type=int, default=0)
     args = ap.parse_args()
     dt = ops.torch_dtype(args.dtype)
     only = args.only.split(",")
     print(f"{'layer':5s} {'shape':28s} " + " ".join(f"{k:>18s}" for k in only))
     for name in args.shapes.split(","):
         B, H, W, Cin, split, Cout = SHAPES[name]
+        if args.batch:
+            B = args.batch
         cp = ops.pad16(split) + ops.pad16(Cin - split) if split else ops.pad16(Cin)
         x = (torch.rand((B, H, W, cp), device="cuda") - 0.3).to(dt)
         w = (torch.rand((Cout, Cin, 3, 3), device="cuda") - 0.5) * 0.1

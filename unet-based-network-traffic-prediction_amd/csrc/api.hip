@@ -76,7 +76,7 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
       h.N = a.N; h.bias = a.epi == E_PLAIN ? nullptr : a.bias; h.n_real = a.n_real; h.relu = a.epi == E_BIAS_RELU;
       h.out = a.out; h.out_cs = a.out_cs; h.out_co = a.out_co;
       h.mask = a.mask; h.mask_cs = a.mask_cs; h.mask_co = a.mask_co;
-      h.W = a.Wi; h.R = R; h.G = G; h.HR = G * (R + 2) * (a.Wi + 2); h.bands = bands;
+      h.W = a.Wi; h.R = R; h.G = G; h.pitch = (a.Wi + 2 + 7) / 8 * 8; h.HR = G * (R + 2) * h.pitch; h.bands = bands;
       h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
       return dtype == MI_BF16 ? launch_hconv_bf16(h, s, name) : launch_hconv_f32(h, s, name);
     }

@@ -4,13 +4,19 @@
 //
 // Difference to the generic implicit-GEMM kernel (igemm_impl.h): the 9 taps do not re-gather
 // the input from global memory.  A workgroup stages ONE zero-ringed halo tile per 64-byte
-// channel chunk in LDS -- (R+2) x (W+2) pixel rows per group of R image rows -- and every tap
-// reads its MFMA pixel fragments from that tile at a constant row offset
-// (ty*(W+2) + tx).  Global->LDS traffic for activations drops from 9x to ~1.3x, and the
-// per-stage MFMA work (9 taps x 16 tiles per wave) is long enough to cover the next stage's
-// loads.  Workgroups are persistent over pixel tiles; when the layer has at most two channel
-// chunks the packed weights of both stay resident in the two LDS stage buffers and are
-// loaded once per workgroup.
+// channel chunk in LDS -- (R+2) rows of `pitch` pixel slots per group of R image rows -- and
+// every tap reads its MFMA pixel fragments from that tile at a constant row offset
+// (ty*pitch + tx).  Global->LDS traffic for activations drops from 9x to ~1.3x.
+//   * pitch is W+2 rounded up to a multiple of 8 slots: a vertical tap shift then leaves the
+//     bank-swizzle bit of a row unchanged, so each lane needs only three precomputed fragment
+//     addresses per pixel tile (tx = 0,1,2) plus a uniform ty offset -- no per-tap address math.
+//   * 512 threads = 8 waves = 2 per SIMD, each wave 2 pixel tiles x TN channel tiles: while
+//     one wave of a SIMD waits on LDS or issues loads/stores, its partner issues MFMAs.
+//   * workgroups are persistent over pixel tiles; when the layer has at most two channel
+//     chunks the packed weights of both stay resident in the two LDS stage buffers and are
+//     loaded once per workgroup.
+//   * padding lanes of the loaders read the zero page (see common.h) so every staging load of
+//     a stage is issued back to back and waited for only at the LDS store after the MFMA phase.
 #pragma once
 #include "igemm_impl.h"
 
@@ -23,112 +29,128 @@ struct HconvArgs {
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;
   int W, R, G;                          // image width, rows per group, groups per tile (G*R*W = 256)
-  int HR;                               // halo rows per tile = G*(R+2)*(W+2)
+  int pitch;                            // halo slots per image row: W+2 rounded up to a multiple of 8
+  int HR;                               // halo slots per tile = G*(R+2)*pitch
   int bands;                            // tiles per image (1 when a tile holds whole images)
   int ntiles, nchunks;
   const void* zero;                     // zero page
 };
 
-constexpr int kHconvMaxHalo = 400;      // halo rows the LDS buffer can hold (covers W <= 64)
+constexpr int kHconvMaxHalo = 640;      // halo slots the LDS buffer can hold (covers 8 <= W <= 64)
 
 template <typename T, int TN>
-__global__ __launch_bounds__(256, 1) void hconv_kernel(const HconvArgs a) {
+__global__ __launch_bounds__(512, 2) void hconv_kernel(const HconvArgs a) {
   typedef typename ElemTraits<T>::frag_t frag_t;
   constexpr int EPC = ElemTraits<T>::EPC;
   constexpr int CK = 4 * EPC;                    // channels per 64-byte chunk
-  constexpr int TM = 4, BM = 256, BN = TN * 16;
+  constexpr int TM = 2, BM = 256, BN = TN * 16, NT = 512;
   constexpr int A_BYTES = kHconvMaxHalo * 64;
   constexpr int W_BYTES = 9 * BN * 64;
   constexpr int STAGE = A_BYTES + W_BYTES;
-  constexpr int A_IT = (kHconvMaxHalo * 4 + 255) / 256;
-  constexpr int W_IT = (9 * BN * 4 + 255) / 256;
+  constexpr int A_IT = (kHconvMaxHalo * 4 + NT - 1) / NT;
+  constexpr int W_IT = (9 * BN * 4 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ in = (const T*)a.in;
   const T* __restrict__ wp = (const T*)a.w;
-  const int Wp2 = a.W + 2;
-  const int grp_rows = (a.R + 2) * Wp2;
+  const int grp_rows = (a.R + 2) * a.pitch;
+  const int chq = (t & 3) * EPC;   // element offset of this thread's 16-byte chunk within the 64-byte row
+  // zero page as element offsets from each operand's base (integer offset select, one base pointer)
+  const int64_t zoff_in = ((intptr_t)a.zero - (intptr_t)a.in) / (int64_t)sizeof(T);
+  const int64_t zoff_w = ((intptr_t)a.zero - (intptr_t)a.w) / (int64_t)sizeof(T);
 
-  // ---- loader state: this thread's halo rows (fixed for every tile)
-  int rel[A_IT];          // pixel offset relative to the tile's first pixel
+  // ---- loader state: this thread's halo slots (fixed for every tile)
+  int relcs[A_IT];        // element offset relative to the tile's first pixel (rel_pixel * in_cs)
   int lds_a[A_IT];        // byte offset in the A buffer (multiple of 16) | kind in the low bits, or -1 (slot unused)
                           // kind: 0 interior, 1 always zero, 2 top halo row, 3 bottom halo row
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int id = t + 256 * i;
+    const int id = t + NT * i;
     const int hr = id >> 2, ch = id & 3;
+    relcs[i] = 0; lds_a[i] = -1;
     if (hr < a.HR) {
       const int g = hr / grp_rows, rem = hr - g * grp_rows;
-      const int hy = rem / Wp2, hx = rem - hy * Wp2;
-      rel[i] = g * a.R * a.W + (hy - 1) * a.W + (hx - 1);
-      const int kind = (hx == 0 || hx == a.W + 1) ? 1 : (hy == 0 ? 2 : (hy == a.R + 1 ? 3 : 0));
-      lds_a[i] = (hr * 64 + ((ch ^ ((hr >> 1) & 2)) << 4)) | kind;
-    } else {
-      rel[i] = 0; lds_a[i] = -1;
+      const int hy = rem / a.pitch, hx = rem - hy * a.pitch;
+      if (hx <= a.W + 1) {
+        relcs[i] = (g * a.R * a.W + (hy - 1) * a.W + (hx - 1)) * a.in_cs;
+        const int kind = (hx == 0 || hx == a.W + 1) ? 1 : (hy == 0 ? 2 : (hy == a.R + 1 ? 3 : 0));
+        lds_a[i] = (hr * 64 + ((ch ^ ((hr >> 1) & 2)) << 4)) | kind;
+      }
     }
   }
-  const int chq = (t & 3) * EPC;   // element offset of this thread's 16-byte chunk within the 64-byte row
-  // element offsets of the zero page relative to each operand's base pointer
-  const int64_t zoff_in = ((intptr_t)a.zero - (intptr_t)a.in) / (int64_t)sizeof(T);
-  const int64_t zoff_w = ((intptr_t)a.zero - (intptr_t)a.w) / (int64_t)sizeof(T);
-
-  u32x4_t ra[A_IT], rw[W_IT];
+  // weight loader: row = tap*BN + n of the [9*BN][64 B] chunk image
+  int woff[W_IT];         // element offset of this thread's weight chunk for channel chunk 0, or -1
 #pragma unroll
-  for (int i = 0; i < W_IT; ++i) rw[i] = u32x4_t{0u, 0u, 0u, 0u};
-  auto load_a = [&](int tile, int chunk) {
+  for (int i = 0; i < W_IT; ++i) {
+    const int id = t + NT * i, row = id >> 2;
+    const int tap = row / BN, n = row - tap * BN;
+    woff[i] = row < 9 * BN ? (n0 + n) * a.Kp + tap * a.Cp + chq : -1;
+  }
+
+  // Two staging register sets: the loads of stage s+2 are issued at the start of stage s and
+  // written to LDS at the end of stage s+1, so a load has two MFMA phases to land.
+  typedef u32x4_t a_regs_t[A_IT];
+  typedef u32x4_t w_regs_t[W_IT];
+  a_regs_t ra0, ra1;
+  w_regs_t rw0, rw1;
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) { rw0[i] = u32x4_t{0u, 0u, 0u, 0u}; rw1[i] = u32x4_t{0u, 0u, 0u, 0u}; }
+  auto load_a = [&](a_regs_t& ra, int tile, int chunk) {
     const int band = tile % a.bands;
     const bool top0 = band == 0, bot0 = band == a.bands - 1;
-    const int64_t base = (int64_t)tile * BM;
-    const int coff = a.in_co + chunk * CK + chq;
+    const int64_t base = (int64_t)tile * BM * a.in_cs + a.in_co + chunk * CK + chq;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int kind = lds_a[i] & 3;   // (-1 & 3) == 3 is harmless: the slot is never stored
       const bool zero = lds_a[i] < 0 || kind == 1 || (kind == 2 && top0) || (kind == 3 && bot0);
-      // padding lanes read the zero page: address select before the load, no use of the data
-      // until the LDS store, so all staging loads stay in flight across the MFMA phase
-      // (integer select of the OFFSET from one base pointer: a select between two pointers
-      // makes the optimiser split the load into branches again)
-      const int64_t off = zero ? zoff_in : (base + rel[i]) * a.in_cs + coff;
+      const int64_t off = zero ? zoff_in : base + relcs[i];
       ra[i] = *(const u32x4_t*)(in + opaque_offset(off));
     }
   };
-  auto load_w = [&](int chunk) {
+  auto load_w = [&](w_regs_t& rw, int chunk) {
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-      const int id = t + 256 * i, row = id >> 2;
-      const int tap = row / BN, n = row - tap * BN;
-      const int64_t off = row < 9 * BN ? (int64_t)(n0 + n) * a.Kp + tap * a.Cp + chunk * CK + chq : zoff_w;
+      const int64_t off = woff[i] >= 0 ? (int64_t)woff[i] + chunk * CK : zoff_w;
       rw[i] = *(const u32x4_t*)(wp + opaque_offset(off));
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](const a_regs_t& ra, int buf) {
     char* A = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       if (lds_a[i] >= 0) *(u32x4_t*)(A + (lds_a[i] & ~15)) = ra[i];
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](const w_regs_t& rw, int buf) {
     char* Wt = smem + buf * STAGE + A_BYTES;
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-      const int id = t + 256 * i, row = id >> 2, ch = id & 3;
+      const int id = t + NT * i, row = id >> 2, ch = id & 3;
       if (row < 9 * BN) *(u32x4_t*)(Wt + row * 64 + ((ch ^ ((row >> 1) & 2)) << 4)) = rw[i];
     }
   };
 
-  // ---- compute state: halo row of the top-left tap for this lane's pixel in each of its 4 tiles
+  // ---- compute state: fragment addresses of this lane's pixel in each of its 2 tiles, per tx
   const int r16 = lane & 15, ch = lane >> 4;
-  int hrow[TM];
+  int paddr[TM][3];
+  int out_off[TM], mask_off[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int pl = (wave * TM + j) * 16 + r16;         // pixel index inside the tile
     const int g = pl / (a.R * a.W), rem = pl - g * (a.R * a.W);
     const int y = rem / a.W, x = rem - y * a.W;
-    hrow[j] = g * grp_rows + y * Wp2 + x;
+    const int hrow = g * grp_rows + y * a.pitch + x;   // halo slot of tap (0,0)
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const int hr = hrow + tx;
+      paddr[j][tx] = hr * 64 + ((ch ^ ((hr >> 1) & 2)) << 4);
+    }
+    out_off[j] = pl * a.out_cs + a.out_co + n0 + 4 * ch;
+    mask_off[j] = pl * a.mask_cs + a.mask_co + n0 + 4 * ch;
   }
-  const int wfrag_off = r16 * 64 + ((ch ^ ((r16 >> 1) & 2)) << 4);
+  const int wfrag_off = A_BYTES + r16 * 64 + ((ch ^ ((r16 >> 1) & 2)) << 4);
+  const int ty_bytes = a.pitch * 64;
 
   f32x4_t acc[TN][TM];
   auto zero_acc = [&]() {
@@ -138,28 +160,30 @@ __global__ __launch_bounds__(256, 1) void hconv_kernel(const HconvArgs a) {
       for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
   auto compute = [&](int buf) {
-    const char* A = smem + buf * STAGE;
-    const char* Wt = A + A_BYTES;
+    const char* S = smem + buf * STAGE;
+    // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
+    frag_t pf[2][TM], wf[2][TN];
+    auto read_tap = [&](int tap, int set) {
+      const int ty = tap / 3, tx = tap % 3;
+      const char* Sy = S + ty * ty_bytes;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) pf[set][j] = *(const frag_t*)(Sy + paddr[j][tx]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[set][i] = *(const frag_t*)(S + (tap * BN + i * 16) * 64 + wfrag_off);
+    };
+    read_tap(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int shift = (tap / 3) * Wp2 + (tap % 3);
-      frag_t pf[TM], wf[TN];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int hr = hrow[j] + shift;
-        pf[j] = *(const frag_t*)(A + hr * 64 + ((ch ^ ((hr >> 1) & 2)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *(const frag_t*)(Wt + (tap * BN + i * 16) * 64 + wfrag_off);
+      if (tap + 1 < 9) read_tap(tap + 1, (tap + 1) & 1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = mma_slab(wf[i], pf[j], acc[i][j]);
+        for (int j = 0; j < TM; ++j) acc[i][j] = mma_slab(wf[tap & 1][i], pf[tap & 1][j], acc[i][j]);
     }
   };
   T* __restrict__ out = (T*)a.out;
   const T* __restrict__ mask = (const T*)a.mask;
-  // bias of this lane's 4 channels per tile, read once (unconditional clamped loads + select)
+  // bias of this lane's 4 channels per channel tile, read once (clamped unconditional loads)
   f32x4_t biasv[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -175,24 +199,36 @@ __global__ __launch_bounds__(256, 1) void hconv_kernel(const HconvArgs a) {
     }
   }
   auto epilogue = [&](int tile) {
+    T* otile = out + (int64_t)tile * BM * a.out_cs;
+    if (mask != nullptr) {
+      // all mask loads first, then all stores: interleaved, every store would wait for its load
+      const T* mtile = mask + (int64_t)tile * BM * a.mask_cs;
+      f32x4_t mv[TM][TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) mv[j][i] = load4f(mtile + mask_off[j] + i * 16);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          f32x4_t v = acc[i][j] + biasv[i];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = mv[j][i][q] > 0.f ? v[q] : 0.f;
+          store4f(otile + out_off[j] + i * 16, v);
+        }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int64_t p = (int64_t)tile * BM + (wave * TM + j) * 16 + r16;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const int n = n0 + i * 16 + 4 * ch;
-        f32x4_t v = acc[i][j];
-        v += biasv[i];
+        f32x4_t v = acc[i][j] + biasv[i];
         if (a.relu) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
         }
-        if (mask != nullptr) {
-          const f32x4_t mv = load4f(mask + p * a.mask_cs + a.mask_co + n);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
-        }
-        store4f(out + p * a.out_cs + a.out_co + n, v);
+        store4f(otile + out_off[j] + i * 16, v);
       }
     }
   };
@@ -202,36 +238,51 @@ __global__ __launch_bounds__(256, 1) void hconv_kernel(const HconvArgs a) {
   const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int nstages = my_tiles * a.nchunks;
   if (nstages <= 0) return;
-  // when weights are resident and the chunk count is odd (1), stage parity alternates while the
-  // chunk does not: keep a copy in both buffers by loading during the first two stages
-  int tile = blockIdx.x, chunk = 0;
-  load_a(tile, 0);
-  load_w(0);
-  store_a(0);
-  store_w(0);
+  // load cursor: (tile, chunk) of the next stage to fetch
+  int ltile = blockIdx.x, lchunk = 0;
+  auto advance_load = [&]() {
+    if (++lchunk == a.nchunks) { lchunk = 0; ltile += gridDim.x; }
+  };
+  // resident weights: stage parity selects the LDS buffer, so both buffers are filled by the
+  // first two stages (with a single chunk that is the same chunk twice) and never again
+  auto stage_needs_w = [&](int s) { return !w_resident || s < 2; };
+
+  load_a(ra0, ltile, lchunk);
+  load_w(rw0, lchunk);
+  advance_load();
+  store_a(ra0, 0);
+  store_w(rw0, 0);
+  if (nstages > 1) {                       // stage 1 stays in set 0 until the end of stage 0
+    load_a(ra0, ltile, lchunk);
+    if (stage_needs_w(1)) load_w(rw0, lchunk);
+    advance_load();
+  }
   __syncthreads();
   zero_acc();
-  for (int s = 0; s < nstages; ++s) {
-    int ntile = tile, nchunk = chunk + 1;
-    if (nchunk == a.nchunks) { nchunk = 0; ntile = tile + gridDim.x; }
-    const bool more = s + 1 < nstages;
-    const bool need_w = more && (!w_resident || s + 1 < 2);
-    if (more) {
-      load_a(ntile, nchunk);
-      if (need_w) load_w(nchunk);
+  int tile = blockIdx.x, chunk = 0;
+  // `held` carries stage s+1 (already in flight), `fresh` receives stage s+2
+  auto stage = [&](int s, a_regs_t& held_a, w_regs_t& held_w, a_regs_t& fresh_a, w_regs_t& fresh_w) {
+    if (s + 2 < nstages) {
+      load_a(fresh_a, ltile, lchunk);
+      if (stage_needs_w(s + 2)) load_w(fresh_w, lchunk);
+      advance_load();
     }
     compute(s & 1);
+    // LDS stores first: their vmcnt wait must not also cover the epilogue's global stores
+    if (s + 1 < nstages) {
+      store_a(held_a, (s + 1) & 1);
+      if (stage_needs_w(s + 1)) store_w(held_w, (s + 1) & 1);
+    }
     if (chunk == a.nchunks - 1) {
       epilogue(tile);
       zero_acc();
     }
-    if (more) {
-      store_a((s + 1) & 1);
-      if (need_w) store_w((s + 1) & 1);
-    }
     __syncthreads();
-    tile = ntile;
-    chunk = nchunk;
+    if (++chunk == a.nchunks) { chunk = 0; tile += gridDim.x; }
+  };
+  for (int s = 0; s < nstages; s += 2) {
+    stage(s, ra0, rw0, ra1, rw1);
+    if (s + 1 < nstages) stage(s + 1, ra1, rw1, ra0, rw0);
   }
 }
 
@@ -248,7 +299,7 @@ inline bool hconv_tiling(int H, int W, int* R, int* G, int* bands) {
     if (256 % HW != 0) return false;
     *R = H; *G = 256 / HW; *bands = 1;
   }
-  return (*G) * (*R + 2) * (W + 2) <= kHconvMaxHalo;
+  return (*G) * (*R + 2) * ((W + 2 + 7) / 8 * 8) <= kHconvMaxHalo;
 }
 
 template <typename T>
@@ -259,9 +310,9 @@ static int launch_hconv_t(const HconvArgs& a, hipStream_t s, const char** name) 
   const int cap = (256 + ny - 1) / ny;          // one workgroup per CU
   if (gx > cap) gx = cap;
   dim3 grid(gx, ny);
-  if (bn == 64) { if (name) *name = "hconv_256x64"; hipLaunchKernelGGL((hconv_kernel<T, 4>), grid, dim3(256), 0, s, a); }
-  else if (bn == 32) { if (name) *name = "hconv_256x32"; hipLaunchKernelGGL((hconv_kernel<T, 2>), grid, dim3(256), 0, s, a); }
-  else { if (name) *name = "hconv_256x16"; hipLaunchKernelGGL((hconv_kernel<T, 1>), grid, dim3(256), 0, s, a); }
+  if (bn == 64) { if (name) *name = "hconv_256x64"; hipLaunchKernelGGL((hconv_kernel<T, 4>), grid, dim3(512), 0, s, a); }
+  else if (bn == 32) { if (name) *name = "hconv_256x32"; hipLaunchKernelGGL((hconv_kernel<T, 2>), grid, dim3(512), 0, s, a); }
+  else { if (name) *name = "hconv_256x16"; hipLaunchKernelGGL((hconv_kernel<T, 1>), grid, dim3(512), 0, s, a); }
   return check_hip(hipGetLastError(), "hconv launch");
 }
 

@@ -151,21 +151,36 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
 
   auto compute = [&](int buf) {
     const char* S = smem + buf * STAGE;
+    // software pipeline over the flattened (k-step, tap) sequence: the fragments of step i+1
+    // are read while the MFMAs of step i issue (two register sets, static indices)
+    bf16x8_t af[2][2], bfr[2];
+    auto read_a = [&](int k, int set) {
+      af[set][0] = tr_pair(S + a_addr[k][0][0], S + a_addr[k][0][1]);
+      af[set][1] = tr_pair(S + a_addr[k][1][0], S + a_addr[k][1][1]);
+    };
+    auto read_b = [&](int k, int tp, int set) {
+      const char* Sy = S + (tp / 3) * ty_bytes;
+      bfr[set] = tr_pair(Sy + b_addr[k][0][tp % 3], Sy + b_addr[k][1][tp % 3]);
+    };
+    read_a(0, 0);
+    read_b(0, 0, 0);
 #pragma unroll
     for (int k = 0; k < KSP; ++k) {
-      const bf16x8_t a0 = tr_pair(S + a_addr[k][0][0], S + a_addr[k][0][1]);
-      const bf16x8_t a1 = tr_pair(S + a_addr[k][1][0], S + a_addr[k][1][1]);
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
-        const int ty = tp / 3, tx = tp % 3;
-        const char* Sy = S + ty * ty_bytes;
-        const bf16x8_t b = tr_pair(Sy + b_addr[k][0][tx], Sy + b_addr[k][1][tx]);
-        acc[tp][0] = mma_px(a0, b, acc[tp][0]);
-        acc[tp][1] = mma_px(a1, b, acc[tp][1]);
+        const int idx = k * 9 + tp;
+        if (tp + 1 < 9) {
+          read_b(k, tp + 1, (idx + 1) & 1);
+        } else if (k + 1 < KSP) {
+          read_a(k + 1, (k + 1) & 1);
+          read_b(k + 1, 0, (idx + 1) & 1);
+        }
+        acc[tp][0] = mma_px(af[k & 1][0], bfr[idx & 1], acc[tp][0]);
+        acc[tp][1] = mma_px(af[k & 1][1], bfr[idx & 1], acc[tp][1]);
       }
       if (do_rows) {
-        accr[0] = mma_px(a0, ones, accr[0]);
-        accr[1] = mma_px(a1, ones, accr[1]);
+        accr[0] = mma_px(af[k & 1][0], ones, accr[0]);
+        accr[1] = mma_px(af[k & 1][1], ones, accr[1]);
       }
     }
   };
