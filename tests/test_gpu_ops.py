@@ -40,7 +40,12 @@ def gen(*shape, seed=0, scale=1.0, shift=0.0):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(3, 20, 24, 9, 7, 0), (2, 12, 32, 16, 16, 0), (2, 40, 8, 5, 6, 24),
-                                   (5, 64, 64, 2, 2, 0), (1, 3, 70, 11, 13, 0)])
+                                   (5, 64, 64, 2, 2, 0), (1, 3, 70, 11, 13, 0),
+                                   # tiny images: position-major kernels (batch tails, non-square, concat, both K splits)
+                                   (70, 128, 64, 4, 4, 0), (3, 128, 128, 2, 4, 64), (600, 64, 128, 4, 4, 0),
+                                   (130, 64, 64, 1, 3, 0),
+                                   # 4x4 images, 16 per halo tile (the wide-halo variant of the tile kernel)
+                                   (32, 64, 96, 4, 4, 0), (48, 32, 16, 4, 4, 0), (16, 128, 64, 4, 4, 64)])
 def test_conv3x3_fwd_dgrad_wgrad(ua, dtype, shape):
     B, Cin, Cout, H, W, split = shape
     ops = ua.ops

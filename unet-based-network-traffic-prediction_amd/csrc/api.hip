@@ -3,6 +3,7 @@
 // wgrad_*.hip and pointwise.hip.
 #include "common.h"
 #include "hconv_impl.h"
+#include "pconv_impl.h"
 
 #include <cstdio>
 #include <cstring>
@@ -26,6 +27,8 @@ int launch_igemm_f32(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
+int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
+int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_f32(const WgradArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_bf16(const WgradArgs& a, hipStream_t s, const char** name);
 
@@ -80,6 +83,21 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
       h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
       return dtype == MI_BF16 ? launch_hconv_bf16(h, s, name) : launch_hconv_f32(h, s, name);
     }
+  }
+  // other 3x3 stride-1 convolutions on images of at most 16 pixels take the position-major kernel
+  // (skips the taps that fall on the padding, splits K inside the workgroup)
+  if (a.mode == G_3x3 && a.epi != E_SHUFFLE_BIAS && a.Hi == a.Ho && a.Wi == a.Wo && a.Hi * a.Wi <= kPconvMaxHW &&
+      a.N % 64 == 0 && a.Cin % (dtype == MI_BF16 ? 64 : 32) == 0 && a.Kp == 9 * a.Cin) {
+    PconvArgs p{};
+    p.in = a.in; p.in_cs = a.in_cs; p.in_co = a.in_co;
+    p.w = a.w; p.Kp = a.Kp; p.Cp = a.Cin;
+    p.N = a.N; p.bias = a.epi == E_PLAIN ? nullptr : a.bias; p.n_real = a.n_real; p.relu = a.epi == E_BIAS_RELU;
+    p.out = a.out; p.out_cs = a.out_cs; p.out_co = a.out_co;
+    p.mask = a.mask; p.mask_cs = a.mask_cs; p.mask_co = a.mask_co;
+    p.B = a.B; p.H = a.Hi; p.W = a.Wi;
+    p.img_tiles = (a.B + 63) / 64; p.n_tiles = a.N / 64;
+    p.units = a.Hi * a.Wi * p.img_tiles * p.n_tiles;
+    return dtype == MI_BF16 ? launch_pconv_bf16(p, s, name) : launch_pconv_f32(p, s, name);
   }
   return dtype == MI_BF16 ? launch_igemm_bf16(a, s, name) : launch_igemm_f32(a, s, name);
 }

@@ -36,18 +36,19 @@ struct HconvArgs {
   const void* zero;                     // zero page
 };
 
-constexpr int kHconvMaxHalo = 640;      // halo slots the LDS buffer can hold (covers 8 <= W <= 64)
+constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 64)
+constexpr int kHconvBigHalo = 768;      // 4x4 images (16 per tile, pitch 8): needs the narrower channel tiles
 
-template <typename T, int TN>
+template <typename T, int TN, int MH>
 __global__ __launch_bounds__(512, 2) void hconv_kernel(const HconvArgs a) {
   typedef typename ElemTraits<T>::frag_t frag_t;
   constexpr int EPC = ElemTraits<T>::EPC;
   constexpr int CK = 4 * EPC;                    // channels per 64-byte chunk
   constexpr int TM = 2, BM = 256, BN = TN * 16, NT = 512;
-  constexpr int A_BYTES = kHconvMaxHalo * 64;
+  constexpr int A_BYTES = MH * 64;
   constexpr int W_BYTES = 9 * BN * 64;
   constexpr int STAGE = A_BYTES + W_BYTES;
-  constexpr int A_IT = (kHconvMaxHalo * 4 + NT - 1) / NT;
+  constexpr int A_IT = (MH * 4 + NT - 1) / NT;
   constexpr int W_IT = (9 * BN * 4 + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void hconv_kernel(const HconvArgs a) {
 
 // Tiling of an (H, W) image into 256-pixel tiles; returns false when the halo kernel does not apply.
 inline bool hconv_tiling(int H, int W, int* R, int* G, int* bands) {
-  if (W < 8 || W > 64) return false;
+  if (W < 4 || W > 64) return false;
   const int HW = H * W;
   if (HW >= 256) {
     if (256 % W != 0) return false;
@@ -299,20 +300,25 @@ inline bool hconv_tiling(int H, int W, int* R, int* G, int* bands) {
     if (256 % HW != 0) return false;
     *R = H; *G = 256 / HW; *bands = 1;
   }
-  return (*G) * (*R + 2) * ((W + 2 + 7) / 8 * 8) <= kHconvMaxHalo;
+  return (*G) * (*R + 2) * ((W + 2 + 7) / 8 * 8) <= kHconvBigHalo;
 }
 
 template <typename T>
 static int launch_hconv_t(const HconvArgs& a, hipStream_t s, const char** name) {
-  const int bn = (a.N % 64 == 0) ? 64 : (a.N % 32 == 0) ? 32 : 16;
+  const bool bighalo = a.HR > kHconvMaxHalo;    // the larger halo buffer leaves LDS room for 32 channels
+  const int bn = (a.N % 64 == 0 && !bighalo) ? 64 : (a.N % 32 == 0) ? 32 : 16;
   const int ny = a.N / bn;
   int gx = a.ntiles;
   const int cap = (256 + ny - 1) / ny;          // one workgroup per CU
   if (gx > cap) gx = cap;
   dim3 grid(gx, ny);
-  if (bn == 64) { if (name) *name = "hconv_256x64"; hipLaunchKernelGGL((hconv_kernel<T, 4>), grid, dim3(512), 0, s, a); }
-  else if (bn == 32) { if (name) *name = "hconv_256x32"; hipLaunchKernelGGL((hconv_kernel<T, 2>), grid, dim3(512), 0, s, a); }
-  else { if (name) *name = "hconv_256x16"; hipLaunchKernelGGL((hconv_kernel<T, 1>), grid, dim3(512), 0, s, a); }
+  if (bighalo) {
+    if (bn == 32) { if (name) *name = "hconv_256x32_h768"; hipLaunchKernelGGL((hconv_kernel<T, 2, kHconvBigHalo>), grid, dim3(512), 0, s, a); }
+    else { if (name) *name = "hconv_256x16_h768"; hipLaunchKernelGGL((hconv_kernel<T, 1, kHconvBigHalo>), grid, dim3(512), 0, s, a); }
+  }
+  else if (bn == 64) { if (name) *name = "hconv_256x64"; hipLaunchKernelGGL((hconv_kernel<T, 4, kHconvMaxHalo>), grid, dim3(512), 0, s, a); }
+  else if (bn == 32) { if (name) *name = "hconv_256x32"; hipLaunchKernelGGL((hconv_kernel<T, 2, kHconvMaxHalo>), grid, dim3(512), 0, s, a); }
+  else { if (name) *name = "hconv_256x16"; hipLaunchKernelGGL((hconv_kernel<T, 1, kHconvMaxHalo>), grid, dim3(512), 0, s, a); }
   return check_hip(hipGetLastError(), "hconv launch");
 }
 

@@ -18,6 +18,7 @@
 // multiplied by the ReLU mask (i.e. they are gradients w.r.t. the conv's pre-activation).
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -78,6 +79,11 @@ struct mi_unet_plan {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
   size_t events_used;
+  // second stream for the weight-gradient kernels of a backward call (see fork_side)
+  hipStream_t side;
+  bool side_tried, side_busy;
+  std::vector<hipEvent_t> sync_pool;
+  size_t sync_used;
 
   int tensor_id(const std::string& n) const {
     for (size_t i = 0; i < tensors.size(); ++i)
@@ -142,15 +148,56 @@ struct Scope {   // brackets one launch with events when profiling is on
     r.kernel = "?"; r.label = label; r.flops = flops; r.bytes = bytes;
     r.e0 = P->event_pool[P->events_used++];
     r.e1 = P->event_pool[P->events_used++];
-    hipEventRecord(r.e0, s);
+    (void)hipEventRecord(r.e0, s);
     P->prof.push_back(r);
     idx = (int)P->prof.size() - 1;
   }
   void kernel(const char* k) { if (idx >= 0 && k) P->prof[idx].kernel = k; }
-  ~Scope() { if (idx >= 0) hipEventRecord(P->prof[idx].e1, s); }
+  ~Scope() { if (idx >= 0) (void)hipEventRecord(P->prof[idx].e1, s); }
 };
 
 double esz(const mi_unet_plan* P) { return (double)elem_size(P->d.dtype); }
+
+// A layer's weight gradient needs its input and its output gradient, and nothing later in the
+// backward pass reads it.  The wgrad kernels therefore run on a second stream beside the dgrad
+// chain: fork_side() makes that stream wait for everything queued so far on the caller's stream
+// (the producer of dy) and returns it; join_side() at the end of the call makes the caller's
+// stream wait for the side stream, so in the caller's stream order the whole call is complete.
+// Per-launch profiling keeps everything on one stream (the timings must not overlap), and so
+// does UNET_TM_SERIAL_BACKWARD=1.
+hipEvent_t next_sync_event(mi_unet_plan* P) {
+  if (P->sync_used == P->sync_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    P->sync_pool.push_back(e);
+  }
+  return P->sync_pool[P->sync_used++];
+}
+hipStream_t fork_side(Run& r) {
+  mi_unet_plan* P = r.P;
+  if (P->profile) return r.s;
+  if (!P->side_tried) {
+    P->side_tried = true;
+    const char* env = getenv("UNET_TM_SERIAL_BACKWARD");
+    if (!(env && env[0] == '1') && hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess) P->side = nullptr;
+  }
+  if (!P->side) return r.s;
+  hipEvent_t e = next_sync_event(P);
+  if (!e || hipEventRecord(e, r.s) != hipSuccess || hipStreamWaitEvent(P->side, e, 0) != hipSuccess) return r.s;
+  P->side_busy = true;
+  return P->side;
+}
+int join_side(Run& r) {
+  mi_unet_plan* P = r.P;
+  if (!P->side_busy) return MI_OK;
+  P->side_busy = false;
+  hipEvent_t e = next_sync_event(P);
+  P->sync_used = 0;   // a wait refers to its event's record at the time of the call: the next call reuses the pool
+  if (!e) return fail(MI_ESTATE, "unet_backward: cannot create an event");
+  int rc = check_hip(hipEventRecord(e, P->side), "unet_backward: event record");
+  if (rc == MI_OK) rc = check_hip(hipStreamWaitEvent(r.s, e, 0), "unet_backward: stream wait");
+  return rc;
+}
 
 #define RUN(expr)                 \
   do {                            \
@@ -184,13 +231,14 @@ int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float a
                   const char* label) {
   const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
   const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
+  hipStream_t ws = fork_side(r);
   for (int phase = 1; phase <= 2; ++phase) {
-    Scope sc(r.P, r.s, phase == 1 ? label : (std::string(label) + ".reduce").c_str(), phase == 1 ? fl : 0.0,
+    Scope sc(r.P, ws, phase == 1 ? label : (std::string(label) + ".reduce").c_str(), phase == 1 ? fl : 0.0,
              phase == 1 ? by : 4.0 * l.cout * l.cin * 9);
     const char* k = phase == 1 ? nullptr : "finalize_conv3";
     int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
                                r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout,
-                               r.P->d.dtype, r.s, phase == 1 ? &k : nullptr, phase);
+                               r.P->d.dtype, ws, phase == 1 ? &k : nullptr, phase);
     sc.kernel(k);
     if (rc) return rc;
   }
@@ -232,6 +280,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   P->forward_done = false;
   P->profile = false;
   P->events_used = 0;
+  P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0;
   P->h.resize(L + 1); P->w.resize(L + 1);
   P->h[0] = d.height; P->w[0] = d.width;
   for (int l = 0; l < L; ++l) { P->h[l + 1] = P->h[l] / 2; P->w[l + 1] = P->w[l] / 2; }
@@ -393,7 +442,9 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
 
 void mi_unet_plan_destroy(mi_unet_plan* plan) {
   if (!plan) return;
-  for (hipEvent_t e : plan->event_pool) hipEventDestroy(e);
+  for (hipEvent_t e : plan->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : plan->sync_pool) (void)hipEventDestroy(e);
+  if (plan->side) (void)hipStreamDestroy(plan->side);
   delete plan;
 }
 size_t mi_unet_plan_workspace_bytes(const mi_unet_plan* plan) { return plan ? plan->ws_bytes : 0; }
@@ -636,13 +687,14 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
       View gprev = j == 0 ? r.view("g.b2") : r.view("g.u2." + std::to_string(j - 1));
       {
         const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
+        hipStream_t ws = fork_side(r);
         for (int phase = 1; phase <= 2; ++phase) {
-          Scope sc(P, r.s, (up.prefix + (phase == 1 ? ".wgrad" : ".wgrad.reduce")).c_str(), phase == 1 ? fl : 0.0,
+          Scope sc(P, ws, (up.prefix + (phase == 1 ? ".wgrad" : ".wgrad.reduce")).c_str(), phase == 1 ? fl : 0.0,
                    phase == 1 ? (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P) : 16.0 * up.cin * up.cout);
           const char* k = phase == 1 ? nullptr : "finalize_convt";
           int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
                                    alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
-                                   r.s, phase == 1 ? &k : nullptr, phase);
+                                   ws, phase == 1 ? &k : nullptr, phase);
           sc.kernel(k);
           RUN(rc);
         }
@@ -700,7 +752,7 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
       }
     }
   }
-  return MI_OK;
+  return join_side(r);
 }
 
 }  // extern "C"
