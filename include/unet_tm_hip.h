@@ -16,8 +16,8 @@
  * (b, y, x, c) of a view lives at  base[((b*H + y)*W + x) * cstride + coff + c].
  * cstride/coff let several tensors share one buffer (the skip and the upsampled half of
  * a decoder input are two channel ranges of one allocation, which is how the concat of
- * models/unet2d.py:86 costs no copy).  Channel counts are padded to multiples of 16;
- * padding channels hold zeros.  dtype selects the storage/compute type of activations
+ * models/unet2d.py:86 costs no copy).  Channel counts are padded (mi_pad_channels: 32 up to 32
+ * channels, multiples of 16 above); padding channels hold zeros.  dtype selects the storage/compute type of activations
  * and packed weights: MI_F32 (fp32 storage, exact-fp32 MFMA) or MI_BF16 (bf16 storage,
  * bf16 MFMA, fp32 accumulate).  Parameters, parameter gradients, the loss and the
  * network input/output are always fp32 in the reference's NCHW / (Cout,Cin,kh,kw) layout.
@@ -45,7 +45,7 @@ typedef struct mi_unet_plan mi_unet_plan;
 
 int mi_version(void);
 const char* mi_last_error(void);
-/* Round a channel count up to the library's padding granule (16). */
+/* Stored channel count of a C-channel NHWC tensor: 32 for C <= 32, else C rounded up to 16. */
 int mi_pad_channels(int c);
 
 /* ------------------------------------------------------------------ layout helpers */

@@ -50,7 +50,7 @@ def main():
         B, H, W, Cin, split, Cout = SHAPES[name]
         if args.batch:
             B = args.batch
-        cp = ops.pad16(split) + ops.pad16(Cin - split) if split else ops.pad16(Cin)
+        cp = ops.pad_ch(split) + ops.pad_ch(Cin - split) if split else ops.pad_ch(Cin)
         x = (torch.rand((B, H, W, cp), device="cuda") - 0.3).to(dt)
         w = (torch.rand((Cout, Cin, 3, 3), device="cuda") - 0.5) * 0.1
         b = torch.rand(Cout, device="cuda") - 0.5

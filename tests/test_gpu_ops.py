@@ -75,7 +75,7 @@ def test_conv3x3_fwd_dgrad_wgrad(ua, dtype, shape):
     dyn = ops.to_nhwc(gy.to(dev), dtype)
     dxn = ops.conv3x3_dgrad(dyn, wb, Cin, Cout, split=split)
     if split:
-        sp = ops.pad16(split)
+        sp = ops.pad_ch(split)
         dx = torch.cat([ops.from_nhwc(dxn, split), ops.from_nhwc(dxn, Cin - split, coff=sp)], dim=1).cpu()
     else:
         dx = ops.from_nhwc(dxn, Cin).cpu()
@@ -157,7 +157,7 @@ def test_convt2x2(ua, dtype, shape):
     xn = ops.to_nhwc(x.cuda(), dtype)
     wf, wb = ops.pack_convt2x2(w.cuda(), dtype)
     # write into the second half of a concat buffer, as the decoder does
-    cp = ops.pad16(Cout)
+    cp = ops.pad_ch(Cout)
     cat = torch.zeros((B, 2 * H, 2 * W, 2 * cp), device="cuda", dtype=dtype)
     ops.convt2x2_fwd(xn, wf, b.cuda(), Cin, Cout, out=cat, out_coff=cp)
     assert rel(ops.from_nhwc(cat, Cout, coff=cp).cpu(), y_ref.detach()) < TOL[dtype]
@@ -250,8 +250,12 @@ def test_layout_roundtrip_and_errors(ua):
     x = gen(3, 12, 5, 7, seed=1)
     for dtype in DTYPES:
         t = ops.to_nhwc(x.cuda(), dtype)
-        assert t.shape == (3, 5, 7, 16) and torch.count_nonzero(t[..., 12:]).item() == 0
+        assert t.shape == (3, 5, 7, ops.pad_ch(12)) and torch.count_nonzero(t[..., 12:]).item() == 0
         assert torch.equal(ops.from_nhwc(t, 12).cpu(), rnd(dtype, x))
+        x2 = gen(2, 40, 4, 6, seed=2)         # 48 stored channels: a partial second block of 32
+        t2 = ops.to_nhwc(x2.cuda(), dtype)
+        assert t2.shape == (2, 4, 6, 48) and torch.count_nonzero(t2[..., 40:]).item() == 0
+        assert torch.equal(ops.from_nhwc(t2, 40).cpu(), rnd(dtype, x2))
     with pytest.raises(RuntimeError):
         ops.to_nhwc(x, torch.float32)          # CPU tensor: no fallback
     # argument errors surface as RuntimeError with the library's message

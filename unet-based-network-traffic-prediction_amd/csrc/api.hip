@@ -144,7 +144,7 @@ IgemmArgs conv3x3_fwd_args(const void* x, int xcs, int xco, const void* wf, cons
   a.Cin = concat_cp(Cin, split);
   a.taps = 9; a.mode = G_3x3;
   a.w = wf; a.Kp = (int)kpad(9 * a.Cin);
-  a.N = pad16(Cout);
+  a.N = pad_ch(Cout);
   a.bias = bias; a.n_real = Cout;
   a.out = y; a.out_cs = ycs; a.out_co = yco;
   a.epi = relu ? E_BIAS_RELU : E_BIAS;
@@ -157,7 +157,7 @@ IgemmArgs conv3x3_dgrad_args(const void* dy, int ycs, int yco, const void* wb, v
   IgemmArgs a{};
   a.in = dy; a.in_cs = ycs; a.in_co = yco;
   a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
-  a.Cin = pad16(Cout);
+  a.Cin = pad_ch(Cout);
   a.taps = 9; a.mode = G_3x3;
   a.w = wb; a.Kp = (int)kpad(9 * a.Cin);
   a.N = concat_cp(Cin, split);
@@ -173,10 +173,10 @@ IgemmArgs convt_fwd_args(const void* x, int xcs, int xco, const void* wf, const 
   IgemmArgs a{};
   a.in = x; a.in_cs = xcs; a.in_co = xco;
   a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W;
-  a.Cin = pad16(Cin);
+  a.Cin = pad_ch(Cin);
   a.taps = 1; a.mode = G_1x1;
   a.w = wf; a.Kp = (int)kpad(a.Cin);
-  a.shufC = pad16(Cout);
+  a.shufC = pad_ch(Cout);
   a.N = 4 * a.shufC;
   a.bias = bias; a.n_real = Cout;
   a.out = y; a.out_cs = ycs; a.out_co = yco;
@@ -190,10 +190,10 @@ IgemmArgs convt_dgrad_args(const void* dy, int ycs, int yco, const void* wb, voi
   IgemmArgs a{};
   a.in = dy; a.in_cs = ycs; a.in_co = yco;
   a.B = B; a.Hi = 2 * H; a.Wi = 2 * W; a.Ho = H; a.Wo = W;
-  a.Cin = pad16(Cout);
+  a.Cin = pad_ch(Cout);
   a.taps = 4; a.mode = G_2x2S2;
   a.w = wb; a.Kp = (int)kpad(4 * a.Cin);
-  a.N = pad16(Cin);
+  a.N = pad_ch(Cin);
   a.out = dx; a.out_cs = dcs; a.out_co = dco;
   a.mask = mask; a.mask_cs = mcs; a.mask_co = mco;
   a.epi = E_PLAIN;
@@ -208,10 +208,11 @@ struct WgradLayout {
   // halo-tile kernel (bf16, evenly tiling images): geometry and slab count
   bool halo;
   int R, G, bands, pitch, HR, tiles_per_split, slabs;
+  bool posmajor;   // tiny images: reduce over the in-bounds pixels of each tap only
 };
 WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
   WgradLayout l{};
-  const int Np = pad16(Cout), Cp = concat_cp(Cin, split), K = 9 * Cp;
+  const int Np = pad_ch(Cout), Cp = concat_cp(Cin, split), K = 9 * Cp;
   const int M = B * H * W;
   if (dtype == MI_BF16 && M % 256 == 0 && Cp % 32 == 0 &&
       hwgrad_tiling(H, W, &l.R, &l.G, &l.bands, &l.pitch, &l.HR) && (l.G == 1 || B % l.G == 0)) {
@@ -221,7 +222,6 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
     const int blocks = nblk * (Cp / 32);                                       // (n-block, c-block) workgroups per split
     int splits = (256 + blocks - 1) / blocks;                                  // about one workgroup per CU
     if (splits > ntiles) splits = ntiles;
-    if (splits > 64) splits = 64;
     l.tiles_per_split = (ntiles + splits - 1) / splits;
     l.splits = (ntiles + l.tiles_per_split - 1) / l.tiles_per_split;
     l.slabs = l.splits * hwgrad_slabs_per_split(Np);
@@ -229,6 +229,7 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
     l.sum_bytes = (size_t)l.slabs * Np * sizeof(float);
     return l;
   }
+  l.posmajor = H * W <= 16 && Cp % 64 == 0;
   l.splits = wgrad_choose_splits(M, Np, K, dtype, &l.pps);
   l.slabs = l.splits;
   l.part_bytes = (size_t)l.splits * Np * K * sizeof(float);
@@ -236,8 +237,8 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
   return l;
 }
 WgradLayout convt_wgrad_layout(int B, int H, int W, int Cin, int Cout, int dtype) {
-  WgradLayout l;
-  const int Cp = pad16(Cin), K = 4 * pad16(Cout);
+  WgradLayout l{};
+  const int Cp = pad_ch(Cin), K = 4 * pad_ch(Cout);
   l.splits = wgrad_choose_splits(B * H * W, Cp, K, dtype, &l.pps);
   l.part_bytes = (size_t)l.splits * Cp * K * sizeof(float);
   l.sum_bytes = (size_t)l.splits * K * sizeof(float);
@@ -250,7 +251,7 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "conv3x3_wgrad: workspace too small");
   if (l.halo) {
     HwgradArgs h{};
-    h.dy = dy; h.dy_cs = ycs; h.dy_co = yco; h.Na = pad16(Cout);
+    h.dy = dy; h.dy_cs = ycs; h.dy_co = yco; h.Na = pad_ch(Cout);
     h.x = x; h.x_cs = xcs; h.x_co = xco; h.Cb = concat_cp(Cin, split);
     h.W = W; h.R = l.R; h.G = l.G; h.pitch = l.pitch; h.HR = l.HR; h.bands = l.bands;
     h.ntiles = B * H * W / 256; h.tiles_per_split = l.tiles_per_split; h.splits = l.splits;
@@ -265,10 +266,11 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
     return launch_finalize_conv3(h.part, h.rowsum, l.slabs, h.Na, h.Cb, Cout, Cin, split, dW, db, alpha, beta, s);
   }
   WgradArgs a{};
-  a.a = dy; a.a_cs = ycs; a.a_co = yco; a.Na = pad16(Cout);
+  a.a = dy; a.a_cs = ycs; a.a_co = yco; a.Na = pad_ch(Cout);
   a.b = x; a.b_cs = xcs; a.b_co = xco; a.Cb = concat_cp(Cin, split);
   a.B = B; a.Hb = H; a.Wb = W; a.Ho = H; a.Wo = W;
-  a.taps = 9; a.mode = G_3x3;
+  a.taps = 9; a.mode = l.posmajor ? G_3x3P : G_3x3;
+  a.divB = make_fastdiv(B);
   a.part = (float*)ws;
   a.rowsum = (float*)((char*)ws + l.part_bytes);
   a.splits = l.splits; a.pix_per_split = l.pps;
@@ -284,8 +286,8 @@ int run_convt_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, in
   const WgradLayout l = convt_wgrad_layout(B, H, W, Cin, Cout, dtype);
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "convt2x2_wgrad: workspace too small");
   WgradArgs a{};
-  a.a = x; a.a_cs = xcs; a.a_co = xco; a.Na = pad16(Cin);
-  a.b = dy; a.b_cs = ycs; a.b_co = yco; a.Cb = pad16(Cout);
+  a.a = x; a.a_cs = xcs; a.a_co = xco; a.Na = pad_ch(Cin);
+  a.b = dy; a.b_cs = ycs; a.b_co = yco; a.Cb = pad_ch(Cout);
   a.B = B; a.Hb = 2 * H; a.Wb = 2 * W; a.Ho = H; a.Wo = W;
   a.taps = 4; a.mode = G_2x2S2;
   a.part = (float*)ws;
@@ -306,11 +308,11 @@ extern "C" {
 
 int mi_version(void) { return 100; }
 const char* mi_last_error(void) { return g_last_error.c_str(); }
-int mi_pad_channels(int c) { return pad16(c); }
+int mi_pad_channels(int c) { return pad_ch(c); }
 
 int mi_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype, mi_stream s) {
   MI_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad arguments");
-  MI_REQUIRE(cs % 16 == 0 && co % 16 == 0 && co + pad16(C) <= cs, "nchw_to_nhwc: bad view");
+  MI_REQUIRE(cs % 16 == 0 && co % 16 == 0 && co + pad_ch(C) <= cs, "nchw_to_nhwc: bad view");
   return launch_nchw_to_nhwc(src, dst, cs, co, B, C, H, W, dtype, (hipStream_t)s);
 }
 int mi_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W, int dtype, mi_stream s) {
@@ -319,11 +321,11 @@ int mi_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, i
 }
 
 size_t mi_packed_conv3x3_bytes(int Cout, int Cin, int split, int dtype, int which) {
-  const int Np = pad16(Cout), Cp = concat_cp(Cin, split);
+  const int Np = pad_ch(Cout), Cp = concat_cp(Cin, split);
   return (size_t)(which == 0 ? (int64_t)Np * kpad(9 * Cp) : (int64_t)Cp * kpad(9 * Np)) * elem_size(dtype);
 }
 size_t mi_packed_convt2x2_bytes(int Cin, int Cout, int dtype, int which) {
-  const int Np = pad16(Cout), Cp = pad16(Cin);
+  const int Np = pad_ch(Cout), Cp = pad_ch(Cin);
   return (size_t)(which == 0 ? (int64_t)4 * Np * kpad(Cp) : (int64_t)Cp * kpad(4 * Np)) * elem_size(dtype);
 }
 int mi_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype, mi_stream s) {

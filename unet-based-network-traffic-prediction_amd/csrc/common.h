@@ -9,8 +9,10 @@
 
 namespace mi {
 
-constexpr int kPad = 16;  // channel padding granule (elements)
-inline int pad16(int c) { return (c + kPad - 1) / kPad * kPad; }
+// Channel padding of NHWC tensors and packed weights: up to 32 channels are stored as 32 (one
+// bf16 MFMA k-step, the narrowest width the halo-tile kernels take), wider tensors round up to 16.
+constexpr int kPad = 16;
+__host__ __device__ inline int pad_ch(int c) { return c <= 32 ? 32 : (c + kPad - 1) / kPad * kPad; }
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 inline int elem_size(int dtype) { return dtype == MI_BF16 ? 2 : 4; }
 
@@ -60,7 +62,8 @@ int check_hip(hipError_t e, const char* what);
 
 // ---------------------------------------------------------------- implicit-GEMM (igemm.hip)
 // out[p][n] = epilogue( sum_{tap,c} in[gather(p,tap)][c] * w[n][tap*Cin + c] )
-enum GatherMode { G_3x3 = 0, G_2x2S2 = 1, G_1x1 = 2 };
+enum GatherMode { G_3x3 = 0, G_2x2S2 = 1, G_1x1 = 2,
+                  G_3x3P = 3 };  // wgrad only: 3x3 on tiny images, reduction over the in-bounds pixels of the tap
 enum Epilogue { E_PLAIN = 0, E_BIAS = 1, E_BIAS_RELU = 2, E_SHUFFLE_BIAS = 3 };
 
 struct IgemmArgs {
@@ -97,7 +100,7 @@ struct WgradArgs {
   float* colsum;                           // [splits][K] or null
   int splits, pix_per_split;
   int M;
-  FastDiv divHW, divW;
+  FastDiv divHW, divW, divB;
   const void* zero;                        // zero page (filled in by launch_wgrad)
 };
 // Halo-tile weight gradient (hwgrad_bf16.hip): 3x3 convs on evenly tiling images, bf16 only.
@@ -131,6 +134,16 @@ int launch_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int 
 int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype,
                         hipStream_t s);
 int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, hipStream_t s);
+// Packing of many layers in one launch (the table is passed by value in the kernel arguments).
+constexpr int kMaxPackJobs = 40;
+struct PackJob {
+  const float* w; void* wf; void* wb;    // wf / wb may be null (that image is not produced)
+  int convt, Cout, Cin, split, Np, Cp, Kp, Kp2;
+  int chunk_end;                         // running count of 1024-element chunks up to and including this job
+};
+struct PackJobs { int n; PackJob job[kMaxPackJobs]; };
+int pack_jobs_add(PackJobs& J, const float* w, void* wfwd, void* wbwd, int convt, int Cout, int Cin, int split);
+int launch_pack_multi(const PackJobs& J, int dtype, hipStream_t s);
 int launch_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W,
                         int C, int dtype, hipStream_t s);
 int launch_maxpool2_bwd(const void* x, int xcs, int xco, const void* dyp, int pcs, int pco,
@@ -157,7 +170,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 
 // Packed-weight geometry helpers (elements)
 inline int concat_cp(int Cin, int split) {  // padded input channels incl. concat layout
-  return split > 0 ? pad16(split) + pad16(Cin - split) : pad16(Cin);
+  return split > 0 ? pad_ch(split) + pad_ch(Cin - split) : pad_ch(Cin);
 }
 inline int64_t kpad(int64_t k) { return round_up(k, 64); }
 

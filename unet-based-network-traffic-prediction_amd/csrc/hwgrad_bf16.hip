@@ -13,8 +13,9 @@
 // a vertical tap shift then leaves the swizzle bits unchanged and becomes an immediate
 // offset; the three horizontal shifts use three precomputed addresses.
 // Each wave keeps 2 n-tiles x 1 c-tile x 9 taps of accumulators; waves that share an
-// accumulator block split the tile's pixels and write separate partial slabs, which the
-// fixed-order combine pass sums (bitwise repeatable, no atomics).
+// accumulator block split the tile's pixels and are summed through LDS at the end, so a
+// workgroup writes one partial slab; the slabs of the pixel splits are summed by the
+// fixed-order combine pass (bitwise repeatable, no atomics).
 #include "wgrad_impl.h"
 #include "hconv_impl.h"
 
@@ -201,9 +202,47 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
     }
   }
 
-  // ---- write this wave's partial slab: D row = n (4*(lane>>4)+j), col = c (lane & 15)
+  // ---- combine the PG pixel groups of every accumulator block through LDS, upper half into
+  // lower half, in a fixed order; the staging buffers are free after the last barrier
+  constexpr int RV = 9 * 2 * 4 + 8;            // accumulator floats per lane (acc + accr)
+  static_assert((PG / 2) * COMBOS * RV * 256 <= 2 * STAGE, "combine buffer must fit in the staging area");
+  float* red = (float*)smem;
+#pragma unroll
+  for (int half = PG / 2; half >= 1; half >>= 1) {
+    if (pg >= half && pg < 2 * half) {
+      float* dst = red + ((pg - half) * COMBOS + combo) * (RV * 64) + lane;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dst[((tp * 2 + nt) * 4 + j) * 64] = acc[tp][nt][j];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(72 + nt * 4 + j) * 64] = accr[nt][j];
+    }
+    __syncthreads();
+    if (pg < half) {
+      const float* src = red + (pg * COMBOS + combo) * (RV * 64) + lane;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[tp][nt][j] += src[((tp * 2 + nt) * 4 + j) * 64];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accr[nt][j] += src[(72 + nt * 4 + j) * 64];
+    }
+    __syncthreads();
+  }
+  if (pg != 0) return;
+
+  // ---- write the workgroup's partial slab: D row = n (4*(lane>>4)+j), col = c (lane & 15)
   const int K = 9 * a.Cb;
-  const int slab = z * PG + pg;
+  const int slab = z;
   float* part = a.part + (int64_t)slab * a.Na * K;
   const int c = c0 + ct * 16 + i16;
 #pragma unroll
@@ -234,7 +273,7 @@ bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR
   *HR = (*G) * (*R + 2) * (*pitch);
   return *HR <= kHwMaxHalo;
 }
-int hwgrad_slabs_per_split(int Na) { return Na % 64 == 0 ? 2 : 4; }
+int hwgrad_slabs_per_split(int) { return 1; }
 
 int launch_hwgrad_bf16(const HwgradArgs& a, hipStream_t s, const char** name) {
   if (a.Na % 64 == 0) {

@@ -110,7 +110,7 @@ int add_tensor(mi_unet_plan* P, const std::string& name, int B, int H, int W, in
                int cs_override = 0) {
   Tensor t;
   t.name = name; t.B = B; t.H = H; t.W = W; t.C = C; t.layout = layout;
-  t.cs = layout == 0 ? (cs_override ? cs_override : pad16(C)) : C;
+  t.cs = layout == 0 ? (cs_override ? cs_override : pad_ch(C)) : C;
   t.bytes = (size_t)B * H * W * t.cs * (layout == 0 ? elem_size(P->d.dtype) : 4);
   t.off = cursor;
   cursor = align_up(cursor + t.bytes, 256);
@@ -260,7 +260,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   MI_REQUIRE(d.in_channels > 0 && d.out_channels > 0 && d.batch > 0 && d.height > 0 && d.width > 0,
              "plan_create: bad shape");
   MI_REQUIRE(d.dtype == MI_F32 || d.dtype == MI_BF16, "plan_create: bad dtype");
-  MI_REQUIRE(d.out_channels <= 16 && pad16(d.features[0]) <= 64, "plan_create: head supports features[0] <= 64, out_channels <= 16");
+  MI_REQUIRE(d.out_channels <= 16 && pad_ch(d.features[0]) <= 64, "plan_create: head supports features[0] <= 64, out_channels <= 16");
   for (int i = 0; i < d.n_levels; ++i) {
     MI_REQUIRE(d.features[i] > 0, "plan_create: features must be positive");
     // The reference only runs when widths double (ConvTranspose2d(2f, f) consumes the
@@ -343,7 +343,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   for (int l = 0; l < L; ++l) {
     const int f = d.features[l];
     add_tensor(P, "a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
-    add_tensor(P, "cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad16(f));
+    add_tensor(P, "cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
     add_tensor(P, "pool." + std::to_string(l), B, P->h[l + 1], P->w[l + 1], f, 0, cur);
   }
   add_tensor(P, "b1", B, P->h[L], P->w[L], 2 * fb, 0, cur);
@@ -374,7 +374,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   for (int l = 0; l < L; ++l) {
     const int f = d.features[l];
     add_tensor(P, "g.a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
-    add_tensor(P, "g.cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad16(f));
+    add_tensor(P, "g.cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
     add_tensor(P, "g.pool." + std::to_string(l), B, P->h[l + 1], P->w[l + 1], f, 0, cur);
   }
   add_tensor(P, "g.b1", B, P->h[L], P->w[L], 2 * fb, 0, cur);
@@ -426,10 +426,10 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     for (int j = 0; j < L; ++j) {
       const int l = L - 1 - j, f = d.features[l]; const std::string s = std::to_string(j), sl = std::to_string(l);
       if (P->direct[j]) {
-        name_view(a + "ups." + std::to_string(2 * j), t + "cat." + sl, pad16(f), f);
+        name_view(a + "ups." + std::to_string(2 * j), t + "cat." + sl, pad_ch(f), f);
       } else {
         name_view(a + "ups." + std::to_string(2 * j), t + "upraw." + s, 0, f);
-        name_view(a + "align." + s, t + "cat." + sl, pad16(f), f);
+        name_view(a + "align." + s, t + "cat." + sl, pad_ch(f), f);
       }
       name_view(a + "ups." + std::to_string(2 * j + 1) + ".1", t + "u1." + s, 0, f);
       name_view(a + "ups." + std::to_string(2 * j + 1) + ".3", t + "u2." + s, 0, f);
@@ -527,12 +527,14 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
     const bool train = (flags & MI_FWD_TRAIN) != 0;
     Scope sc(P, r.s, "pack_weights", 0, 0);
     sc.kernel("pack");
+    PackJobs J;
+    J.n = 0;
     for (const auto& l : P->layers) {
-      if (l.kind == K_CONV3)
-        RUN(launch_pack_conv3x3(r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.cout, l.cin, l.split, dt, r.s));
-      else if (l.kind == K_CONVT)
-        RUN(launch_pack_convt2x2(r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.cin, l.cout, dt, r.s));
+      if (l.kind != K_CONV3 && l.kind != K_CONVT) continue;
+      if (J.n == kMaxPackJobs) { RUN(launch_pack_multi(J, dt, r.s)); J.n = 0; }
+      pack_jobs_add(J, r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.kind == K_CONVT, l.cout, l.cin, l.split);
     }
+    RUN(launch_pack_multi(J, dt, r.s));
   }
   {
     Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
@@ -565,7 +567,7 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
     cur = b2;
   }
   for (int j = 0; j < L; ++j) {
-    const int l = L - 1 - j, f = d.features[l], fp = pad16(f);
+    const int l = L - 1 - j, f = d.features[l], fp = pad_ch(f);
     const std::string s = std::to_string(j), sl = std::to_string(l);
     const Layer& up = P->layers[P->layer_id("ups." + std::to_string(2 * j))];
     const Layer& c1 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".0")];
@@ -657,7 +659,7 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
                           r.ws + P->scratch_off, P->scratch_bytes, B, d.height, d.width, hd.cin, hd.cout, 1, dt, r.s));
     } else if (seg <= L) {
       // ---- decoder block j (levels from the output side inwards)
-      const int j = L - seg, l = L - 1 - j, f = d.features[l], fp = pad16(f);
+      const int j = L - seg, l = L - 1 - j, f = d.features[l], fp = pad_ch(f);
       const std::string s = std::to_string(j), sl = std::to_string(l);
       const Layer& up = P->layers[P->layer_id("ups." + std::to_string(2 * j))];
       const Layer& c1 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".0")];

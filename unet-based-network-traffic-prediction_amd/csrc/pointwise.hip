@@ -27,21 +27,23 @@ template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
                                     int64_t npix, int C, int Cp, int HW) {
-  // one thread per (pixel, group of 4 channels); consecutive threads walk pixels so the
-  // NCHW reads are coalesced per channel plane.
-  const int groups = Cp / 4;
-  const int64_t total = npix * groups;
+  // one thread per (pixel, block of 32 channels): consecutive threads walk pixels, so every
+  // channel-plane read is coalesced, and a thread writes its pixel's 32 channels as whole
+  // 16-byte pieces of one contiguous row segment.
+  const int blocks = (Cp + 31) / 32;
+  const int64_t total = npix * blocks;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i % npix;
-    const int g = (int)(i / npix);
+    const int c0 = (int)(i / npix) * 32;
     const int64_t b = p / HW, r = p % HW;
-    f32x4_t v;
+    const float* sp = src + (b * C + c0) * HW + r;
+    float v[32];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = g * 4 + q;
-      v[q] = c < C ? src[(b * C + c) * HW + r] : 0.f;
-    }
-    store4f(dst + p * cs + co + g * 4, v);
+    for (int q = 0; q < 32; ++q) v[q] = c0 + q < C ? sp[(int64_t)q * HW] : 0.f;
+    T* dp = dst + p * cs + co + c0;
+#pragma unroll
+    for (int q = 0; q < 32; q += 4)
+      if (c0 + q < Cp) store4f(dp + q, f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]});
   }
 }
 template <typename T>
@@ -58,8 +60,8 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int cs, int co, f
 int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype,
                         hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
-  const int Cp = pad16(C);
-  const int grid = grid_for(npix * (Cp / 4));
+  const int Cp = pad_ch(C);
+  const int grid = grid_for(npix * ((Cp + 31) / 32), 256, 256 * 16);
   if (dtype == MI_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, npix, C, Cp, H * W);
   else
@@ -90,57 +92,121 @@ __device__ __forceinline__ int unpos(int pos, int Cin, int split, int split_pad)
   return pos < Cin ? pos : -1;
 }
 template <typename T>
+__device__ __forceinline__ void pack_conv3x3_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
+                                                  int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2,
+                                                  int64_t i, int64_t nf) {
+  const int split_pad = pad_ch(split);
+  if (i < nf) {
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    const int tap = k / Cp, pos = k % Cp;
+    float v = 0.f;
+    if (n < Cout && tap < 9) {
+      const int ci = unpos(pos, Cin, split, split_pad);
+      if (ci >= 0) v = w[((int64_t)n * Cin + ci) * 9 + tap];
+    }
+    wf[i] = from_f<T>(v);
+  } else {
+    const int64_t j = i - nf;
+    const int pos = (int)(j / Kp2), k = (int)(j % Kp2);
+    const int tap = k / Np, co = k % Np;
+    float v = 0.f;
+    if (tap < 9 && co < Cout) {
+      const int ci = unpos(pos, Cin, split, split_pad);
+      if (ci >= 0) v = w[((int64_t)co * Cin + ci) * 9 + (8 - tap)];
+    }
+    wb[j] = from_f<T>(v);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void pack_convt2x2_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
+                                                   int Cin, int Cout, int Np, int Cp, int Kp, int Kp2, int64_t i,
+                                                   int64_t nf) {
+  if (i < nf) {
+    const int row = (int)(i / Kp), ci = (int)(i % Kp);
+    const int g = row / Np, co = row % Np;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((int64_t)ci * Cout + co) * 4 + g];
+    wf[i] = from_f<T>(v);
+  } else {
+    const int64_t j = i - nf;
+    const int ci = (int)(j / Kp2), k = (int)(j % Kp2);
+    const int g = k / Np, co = k % Np;
+    float v = 0.f;
+    if (ci < Cin && g < 4 && co < Cout) v = w[((int64_t)ci * Cout + co) * 4 + g];
+    wb[j] = from_f<T>(v);
+  }
+}
+template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
                                     int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2) {
-  const int split_pad = (split + 15) / 16 * 16;
   const int64_t nf = wf ? (int64_t)Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < nf) {
-      const int n = (int)(i / Kp), k = (int)(i % Kp);
-      const int tap = k / Cp, pos = k % Cp;
-      float v = 0.f;
-      if (n < Cout && tap < 9) {
-        const int ci = unpos(pos, Cin, split, split_pad);
-        if (ci >= 0) v = w[((int64_t)n * Cin + ci) * 9 + tap];
-      }
-      wf[i] = from_f<T>(v);
-    } else {
-      const int64_t j = i - nf;
-      const int pos = (int)(j / Kp2), k = (int)(j % Kp2);
-      const int tap = k / Np, co = k % Np;
-      float v = 0.f;
-      if (tap < 9 && co < Cout) {
-        const int ci = unpos(pos, Cin, split, split_pad);
-        if (ci >= 0) v = w[((int64_t)co * Cin + ci) * 9 + (8 - tap)];
-      }
-      wb[j] = from_f<T>(v);
-    }
-  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x)
+    pack_conv3x3_elem<T>(w, wf, wb, Cout, Cin, split, Np, Cp, Kp, Kp2, i, nf);
 }
 template <typename T>
 __global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
                                      int Cin, int Cout, int Np, int Cp, int Kp, int Kp2) {
   const int64_t nf = wf ? (int64_t)4 * Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < nf) {
-      const int row = (int)(i / Kp), ci = (int)(i % Kp);
-      const int g = row / Np, co = row % Np;
-      float v = 0.f;
-      if (co < Cout && ci < Cin) v = w[((int64_t)ci * Cout + co) * 4 + g];
-      wf[i] = from_f<T>(v);
-    } else {
-      const int64_t j = i - nf;
-      const int ci = (int)(j / Kp2), k = (int)(j % Kp2);
-      const int g = k / Np, co = k % Np;
-      float v = 0.f;
-      if (ci < Cin && g < 4 && co < Cout) v = w[((int64_t)ci * Cout + co) * 4 + g];
-      wb[j] = from_f<T>(v);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x)
+    pack_convt2x2_elem<T>(w, wf, wb, Cin, Cout, Np, Cp, Kp, Kp2, i, nf);
+}
+// All layers of a network in one launch: the job table travels in the kernel arguments, a
+// workgroup finds its job from the running chunk counts (1024 packed elements per chunk).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs J) {
+  const int chunk = blockIdx.x;
+  int j = 0;
+  while (j < J.n - 1 && chunk >= J.job[j].chunk_end) ++j;
+  const PackJob& q = J.job[j];
+  const int c0 = j > 0 ? J.job[j - 1].chunk_end : 0;
+  const int64_t base = (int64_t)(chunk - c0) * 1024 + threadIdx.x;
+  T* wf = (T*)q.wf;
+  T* wb = (T*)q.wb;
+  if (q.convt) {
+    const int64_t nf = wf ? (int64_t)4 * q.Np * q.Kp : 0, nb = wb ? (int64_t)q.Cp * q.Kp2 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = base + e * 256;
+      if (i < nf + nb) pack_convt2x2_elem<T>(q.w, wf, wb, q.Cin, q.Cout, q.Np, q.Cp, q.Kp, q.Kp2, i, nf);
+    }
+  } else {
+    const int64_t nf = wf ? (int64_t)q.Np * q.Kp : 0, nb = wb ? (int64_t)q.Cp * q.Kp2 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = base + e * 256;
+      if (i < nf + nb) pack_conv3x3_elem<T>(q.w, wf, wb, q.Cout, q.Cin, q.split, q.Np, q.Cp, q.Kp, q.Kp2, i, nf);
     }
   }
 }
+int pack_jobs_add(PackJobs& J, const float* w, void* wfwd, void* wbwd, int convt, int Cout, int Cin, int split) {
+  if (J.n >= kMaxPackJobs) return 0;
+  PackJob& q = J.job[J.n];
+  q.w = w; q.wf = wfwd; q.wb = wbwd; q.convt = convt; q.Cout = Cout; q.Cin = Cin; q.split = split;
+  int64_t total;
+  if (convt) {
+    q.Np = pad_ch(Cout); q.Cp = pad_ch(Cin); q.Kp = (int)kpad(q.Cp); q.Kp2 = (int)kpad(4 * q.Np);
+    total = (wfwd ? (int64_t)4 * q.Np * q.Kp : 0) + (wbwd ? (int64_t)q.Cp * q.Kp2 : 0);
+  } else {
+    q.Np = pad_ch(Cout); q.Cp = concat_cp(Cin, split); q.Kp = (int)kpad(9 * q.Cp); q.Kp2 = (int)kpad(9 * q.Np);
+    total = (wfwd ? (int64_t)q.Np * q.Kp : 0) + (wbwd ? (int64_t)q.Cp * q.Kp2 : 0);
+  }
+  const int prev = J.n > 0 ? J.job[J.n - 1].chunk_end : 0;
+  q.chunk_end = prev + (int)((total + 1023) / 1024);
+  ++J.n;
+  return 1;
+}
+int launch_pack_multi(const PackJobs& J, int dtype, hipStream_t s) {
+  if (J.n == 0 || J.job[J.n - 1].chunk_end == 0) return MI_OK;
+  const int grid = J.job[J.n - 1].chunk_end;
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(pack_multi_kernel<__bf16>, dim3(grid), dim3(256), 0, s, J);
+  else
+    hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(grid), dim3(256), 0, s, J);
+  return check_hip(hipGetLastError(), "pack_multi");
+}
 int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype,
                         hipStream_t s) {
-  const int Np = pad16(Cout), Cp = concat_cp(Cin, split);
+  const int Np = pad_ch(Cout), Cp = concat_cp(Cin, split);
   const int Kp = (int)kpad(9 * Cp), Kp2 = (int)kpad(9 * Np);
   const int64_t total = (wfwd ? (int64_t)Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
   if (total == 0) return MI_OK;
@@ -152,7 +218,7 @@ int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Ci
   return check_hip(hipGetLastError(), "pack_conv3x3");
 }
 int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, hipStream_t s) {
-  const int Np = pad16(Cout), Cp = pad16(Cin);
+  const int Np = pad_ch(Cout), Cp = pad_ch(Cin);
   const int Kp = (int)kpad(Cp), Kp2 = (int)kpad(4 * Np);
   const int64_t total = (wfwd ? (int64_t)4 * Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
   if (total == 0) return MI_OK;
@@ -244,7 +310,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xcs, int xco, c
 }
 int launch_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C,
                         int dtype, hipStream_t s) {
-  const int Cp = pad16(C);
+  const int Cp = pad_ch(C);
   const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (Cp / 4);
   if (total == 0) return MI_OK;
   const int grid = grid_for(total);
@@ -257,7 +323,7 @@ int launch_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int y
 int launch_maxpool2_bwd(const void* x, int xcs, int xco, const void* dyp, int pcs, int pco, const void* dskip,
                         int scs, int sco, void* dx, int dcs, int dco, int B, int H, int W, int C, int relu_mask,
                         int dtype, hipStream_t s) {
-  const int Cp = pad16(C);
+  const int Cp = pad_ch(C);
   const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (Cp / 4);
   const int grid = grid_for(total);
   if (dtype == MI_BF16)
@@ -304,13 +370,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
 }
 int launch_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,
                     int W, int Cin, int Cout, int dtype, hipStream_t s) {
-  MI_REQUIRE(pad16(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
+  MI_REQUIRE(pad_ch(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
   const int64_t npix = (int64_t)B * H * W;
   const int grid = grid_for(npix);
   if (dtype == MI_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad16(Cin), Cout);
+    hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad_ch(Cin), Cout);
   else
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad16(Cin), Cout);
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad_ch(Cin), Cout);
   return check_hip(hipGetLastError(), "head_fwd");
 }
 
@@ -471,13 +537,13 @@ __global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restri
   }
 }
 constexpr int kHeadBlocks = 512;
-size_t head_ws_bytes(int Cin, int Cout) { return (size_t)kHeadBlocks * (Cout * pad16(Cin) + Cout) * sizeof(float); }
+size_t head_ws_bytes(int Cin, int Cout) { return (size_t)kHeadBlocks * (Cout * pad_ch(Cin) + Cout) * sizeof(float); }
 int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float* dpred, void* dx, int dcs, int dco,
                     float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W,
                     int Cin, int Cout, int relu_mask, int dtype, hipStream_t s) {
-  MI_REQUIRE(pad16(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
+  MI_REQUIRE(pad_ch(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
   if (ws_bytes < head_ws_bytes(Cin, Cout)) return fail(MI_ESIZE, "head_bwd: workspace too small");
-  const int Cp = pad16(Cin);
+  const int Cp = pad_ch(Cin);
   const int64_t npix = (int64_t)B * H * W;
   const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
   const int nblocks = (int)(ntiles < kHeadBlocks ? ntiles : kHeadBlocks);
@@ -736,7 +802,7 @@ __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __rest
                                                               float beta) {
   __shared__ float sh[256];
   const int K = 9 * Cp;
-  const int split_pad = (split + 15) / 16 * 16;
+  const int split_pad = pad_ch(split);
   const int64_t total = (int64_t)Cout * K + Cout;
   const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
   for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
@@ -807,8 +873,50 @@ __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __rest
     __syncthreads();
   }
 }
+// Few splits, large layers: one workgroup per (output channel, 64 packed input positions).  The
+// partial columns are read tap by tap (coalesced), transposed through LDS, and written as one
+// contiguous run of dW[co][ci][3][3].
+__global__ __launch_bounds__(256) void finalize_conv3_wide_kernel(const float* __restrict__ part,
+                                                                   const float* __restrict__ rowsum, int splits,
+                                                                   int Npad, int Cp, int Cout, int Cin, int split,
+                                                                   float* __restrict__ dW, float* __restrict__ db,
+                                                                   float alpha, float beta) {
+  __shared__ float sh[9 * 64];
+  const int K = 9 * Cp;
+  const int co = blockIdx.x, pos0 = blockIdx.y * 64;
+  const int split_pad = pad_ch(split);
+  for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
+    const int tap = idx >> 6, o = idx & 63;
+    float v = 0.f;
+    if (pos0 + o < Cp) {
+      const float* p = part + (int64_t)co * K + tap * Cp + pos0 + o;
+      for (int z = 0; z < splits; ++z) v += p[(int64_t)z * Npad * K];
+    }
+    sh[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
+    const int cl = idx / 9, tap = idx - cl * 9;
+    if (pos0 + cl >= Cp) continue;
+    const int ci = unpos(pos0 + cl, Cin, split, split_pad);
+    if (ci < 0) continue;
+    float* out = dW + ((int64_t)co * Cin + ci) * 9 + tap;
+    *out = alpha * sh[tap * 64 + cl] + (beta != 0.f ? beta * *out : 0.f);
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0 && db != nullptr) {
+    float v = 0.f;
+    if (rowsum)
+      for (int z = 0; z < splits; ++z) v += rowsum[(int64_t)z * Npad + co];
+    db[co] = alpha * v + (beta != 0.f ? beta * db[co] : 0.f);
+  }
+}
 int launch_finalize_conv3(const float* part, const float* rowsum, int splits, int Npad, int Cp, int Cout, int Cin,
                           int split, float* dW, float* db, float alpha, float beta, hipStream_t s) {
+  if (splits <= 8 && (int64_t)Cout * Cp >= 64 * 256) {
+    hipLaunchKernelGGL(finalize_conv3_wide_kernel, dim3(Cout, (Cp + 63) / 64), dim3(256), 0, s, part, rowsum, splits,
+                       Npad, Cp, Cout, Cin, split, dW, db, alpha, beta);
+    return check_hip(hipGetLastError(), "finalize_conv3");
+  }
   const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
   hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, s, part, rowsum, splits, Npad,
                      Cp, Cout, Cin, split, dW, db, alpha, beta);

@@ -9,6 +9,11 @@
 // plain ds_read_b32 for fp32 (v_mfma_f32_16x16x4_f32 wants one float per lane).
 // One workgroup owns a 64(n) x 64(k) output tile for one pixel range; ranges are
 // combined afterwards in a fixed order (bitwise reproducible, no atomics).
+// On images of a few pixels most (pixel, tap) pairs of a 3x3 conv fall on the zero padding
+// (20 of 36 on a 2x2 image).  Mode G_3x3P therefore reduces over a per-tap list instead: a
+// k-tile lies inside one tap (Cb % 64 == 0), and its workgroups walk only the in-bounds
+// positions of that tap, position-major over the batch -- no padding rows are loaded or
+// multiplied.
 // Row sums of a (bias gradient of a conv) and column sums of b (bias gradient of a
 // transposed conv) come from extra MFMAs against an all-ones fragment.
 #pragma once
@@ -97,9 +102,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   // zero page as element offsets from each operand's base (integer offset select, one base pointer)
   const int64_t zoff_a = ((intptr_t)a.zero - (intptr_t)a.a) / (int64_t)sizeof(T);
   const int64_t zoff_b = ((intptr_t)a.zero - (intptr_t)a.b) / (int64_t)sizeof(T);
-  const int pbeg = z * a.pix_per_split;
-  const int pend = min(a.M, pbeg + a.pix_per_split);
-
+  int pbeg = z * a.pix_per_split;
+  int pend = min(a.M, pbeg + a.pix_per_split);
+  // G_3x3P: the reduction index e runs over (valid position, image); [pbeg,pend) is a range of e
+  int vy0 = 0, vx0 = 0, nvx = 1;
+  if (MODE == G_3x3P) {
+    const int tap = k0 / a.Cb;
+    const int ty = tap / 3, ddy = ty - 1, ddx = tap - ty * 3 - 1;
+    vy0 = ddy < 0 ? 1 : 0;
+    vx0 = ddx < 0 ? 1 : 0;
+    nvx = a.Wb - (ddx != 0 ? 1 : 0);
+    const int nvy = a.Hb - (ddy != 0 ? 1 : 0);
+    pend = min(nvy * nvx * a.B, pend);
+  }
   const int cch = t % CPR, row0 = t / CPR;
   // a-operand chunk: channels n0 + cch*EPC ..
   const int an = n0 + cch * EPC;
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const bool b_ok = bk < K;
   int dy = 0, dx = 0;
   int64_t toff = 0;
-  if (MODE == G_3x3) {
+  if (MODE == G_3x3 || MODE == G_3x3P) {
     const int ty = btap / 3;
     dy = ty - 1;
     dx = btap - ty * 3 - 1;
@@ -126,12 +141,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     for (int i = 0; i < IT; ++i) {
       // Loads are unconditional; padding elements read the zero page (address select before the
       // load), so no instruction touches the data until the LDS store after the MFMA phase.
-      const int p = pstage + row0 + i * RPP;
+      int p = pstage + row0 + i * RPP;
       const bool pv = p < pend;
+      if (MODE == G_3x3P) {
+        // e -> (position index, image) -> pixel; every listed pixel has its tap neighbour in bounds
+        const uint32_t e = pv ? (uint32_t)p : 0u;
+        const uint32_t pi = fdiv(e, a.divB);
+        const uint32_t n = e - pi * (uint32_t)a.B;
+        const uint32_t iy = pi / (uint32_t)nvx, ix = pi - iy * (uint32_t)nvx;
+        p = (int)(n * (uint32_t)HW + (vy0 + iy) * (uint32_t)a.Wb + vx0 + ix);
+      }
       const bool av = pv && a_ok;
       bool bv = pv && b_ok;
       int64_t boff = (int64_t)p * a.b_cs;
-      if (MODE != G_1x1) {
+      if (MODE == G_3x3 || MODE == G_2x2S2) {
         const uint32_t pc = pv ? (uint32_t)p : 0u;
         const uint32_t b = fdiv(pc, a.divHW);
         const uint32_t r = pc - b * (uint32_t)HW;
@@ -167,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const bool do_rows = a.rowsum != nullptr && blockIdx.y == 0 && wc == 0;
+  // row sums need every pixel: in G_3x3P only the centre tap's list has them all
+  const int rows_ky = MODE == G_3x3P ? 4 * a.Cb / 64 : 0;
+  const bool do_rows = a.rowsum != nullptr && (int)blockIdx.y == rows_ky && wc == 0;
   const bool do_cols = a.colsum != nullptr && blockIdx.x == 0 && wr == 0;
   const auto ones = ones_frag(T());
 
@@ -248,6 +273,7 @@ static int launch_wgrad_t(const WgradArgs& a, hipStream_t s, const char** name) 
   if (name) *name = "wgrad_64x64";
   switch (a.mode) {
     case G_3x3: hipLaunchKernelGGL((wgrad_kernel<T, G_3x3>), grid, dim3(256), 0, s, a); break;
+    case G_3x3P: if (name) *name = "wgrad_64x64_pos"; hipLaunchKernelGGL((wgrad_kernel<T, G_3x3P>), grid, dim3(256), 0, s, a); break;
     case G_2x2S2: hipLaunchKernelGGL((wgrad_kernel<T, G_2x2S2>), grid, dim3(256), 0, s, a); break;
     case G_1x1: hipLaunchKernelGGL((wgrad_kernel<T, G_1x1>), grid, dim3(256), 0, s, a); break;
     default: return fail(MI_EINVAL, "wgrad: bad gather mode");

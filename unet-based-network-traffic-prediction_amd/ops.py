@@ -1,7 +1,7 @@
 """Thin tensor-level wrappers over the single-operator C entry points.
 
 Activations are torch tensors in the library's layout: NHWC ``(B, H, W, Cpad)`` with
-``Cpad = pad16(C)`` and dtype ``torch.float32`` or ``torch.bfloat16``.  Parameters and
+``Cpad = pad_ch(C)`` and dtype ``torch.float32`` or ``torch.bfloat16``.  Parameters and
 parameter gradients are fp32 in the reference's layouts.  Every function enqueues on the
 current torch stream and returns torch tensors it allocated; nothing here computes
 with torch ops."""
@@ -14,8 +14,9 @@ import torch
 from ._lib import MI_BF16, MI_F32, check, lib
 
 
-def pad16(c: int) -> int:
-    return (c + 15) // 16 * 16
+def pad_ch(c: int) -> int:
+    """Stored channel count of a C-channel tensor (same rule as ``mi_pad_channels``)."""
+    return 32 if c <= 32 else (c + 15) // 16 * 16
 
 
 def mi_dtype(dt: torch.dtype) -> int:
@@ -60,7 +61,7 @@ def to_nhwc(x: torch.Tensor, dtype=torch.float32, out: Optional[torch.Tensor] = 
     x = x.contiguous().float()
     B, Cc, H, W = x.shape
     if out is None:
-        out = torch.empty((B, H, W, pad16(Cc)), device=x.device, dtype=dtype)
+        out = torch.empty((B, H, W, pad_ch(Cc)), device=x.device, dtype=dtype)
     check(lib().mi_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), out.shape[3], coff, B, Cc, H, W,
                                 mi_dtype(out.dtype), _stream()), "nchw_to_nhwc")
     return out
@@ -106,7 +107,7 @@ def pack_convt2x2(weight: torch.Tensor, dtype, want_bwd: bool = True):
 def conv3x3_relu_fwd(x, wfwd, bias, Cin, Cout, split=0, relu=True, out=None, out_coff=0):
     B, H, W, _ = x.shape
     if out is None:
-        out = torch.empty((B, H, W, pad16(Cout)), device=x.device, dtype=x.dtype)
+        out = torch.empty((B, H, W, pad_ch(Cout)), device=x.device, dtype=x.dtype)
     check(lib().mi_conv3x3_relu_fwd(*_view(x), wfwd.data_ptr(), bias.data_ptr(), *_view(out, out_coff),
                                     B, H, W, Cin, split, Cout, int(relu), mi_dtype(x.dtype), _stream()), "conv3x3_fwd")
     return out
@@ -114,7 +115,7 @@ def conv3x3_relu_fwd(x, wfwd, bias, Cin, Cout, split=0, relu=True, out=None, out
 
 def conv3x3_dgrad(dy, wbwd, Cin, Cout, split=0, mask=None, dy_coff=0):
     B, H, W, _ = dy.shape
-    cp = pad16(split) + pad16(Cin - split) if split else pad16(Cin)
+    cp = pad_ch(split) + pad_ch(Cin - split) if split else pad_ch(Cin)
     dx = torch.empty((B, H, W, cp), device=dy.device, dtype=dy.dtype)
     mv = _view(mask) if mask is not None else (None, 0, 0)
     check(lib().mi_conv3x3_dgrad(*_view(dy, dy_coff), wbwd.data_ptr(), *_view(dx), *mv,
@@ -138,14 +139,14 @@ def conv3x3_wgrad(x, dy, Cin, Cout, split=0, dW=None, db=None, alpha=1.0, beta=0
 # ------------------------------------------------------------------ max-pool
 def maxpool2_fwd(x, C, x_coff=0):
     B, H, W, _ = x.shape
-    y = torch.empty((B, H // 2, W // 2, pad16(C)), device=x.device, dtype=x.dtype)
+    y = torch.empty((B, H // 2, W // 2, pad_ch(C)), device=x.device, dtype=x.dtype)
     check(lib().mi_maxpool2_fwd(*_view(x, x_coff), *_view(y), B, H, W, C, mi_dtype(x.dtype), _stream()), "maxpool2_fwd")
     return y
 
 
 def maxpool2_bwd(x, dy_pool, C, dskip=None, relu_mask=False, x_coff=0):
     B, H, W, _ = x.shape
-    dx = torch.empty((B, H, W, pad16(C)), device=x.device, dtype=x.dtype)
+    dx = torch.empty((B, H, W, pad_ch(C)), device=x.device, dtype=x.dtype)
     sv = _view(dskip) if dskip is not None else (None, 0, 0)
     check(lib().mi_maxpool2_bwd(*_view(x, x_coff), *_view(dy_pool), *sv, *_view(dx), B, H, W, C, int(relu_mask),
                                 mi_dtype(x.dtype), _stream()), "maxpool2_bwd")
@@ -156,7 +157,7 @@ def maxpool2_bwd(x, dy_pool, C, dskip=None, relu_mask=False, x_coff=0):
 def convt2x2_fwd(x, wfwd, bias, Cin, Cout, out=None, out_coff=0):
     B, H, W, _ = x.shape
     if out is None:
-        out = torch.empty((B, 2 * H, 2 * W, pad16(Cout)), device=x.device, dtype=x.dtype)
+        out = torch.empty((B, 2 * H, 2 * W, pad_ch(Cout)), device=x.device, dtype=x.dtype)
     check(lib().mi_convt2x2_fwd(*_view(x), wfwd.data_ptr(), bias.data_ptr(), *_view(out, out_coff), B, H, W, Cin, Cout,
                                 mi_dtype(x.dtype), _stream()), "convt2x2_fwd")
     return out
@@ -165,7 +166,7 @@ def convt2x2_fwd(x, wfwd, bias, Cin, Cout, out=None, out_coff=0):
 def convt2x2_dgrad(dy, wbwd, Cin, Cout, mask=None, dy_coff=0):
     B, H2, W2, _ = dy.shape
     H, W = H2 // 2, W2 // 2
-    dx = torch.empty((B, H, W, pad16(Cin)), device=dy.device, dtype=dy.dtype)
+    dx = torch.empty((B, H, W, pad_ch(Cin)), device=dy.device, dtype=dy.dtype)
     mv = _view(mask) if mask is not None else (None, 0, 0)
     check(lib().mi_convt2x2_dgrad(*_view(dy, dy_coff), wbwd.data_ptr(), *_view(dx), *mv, B, H, W, Cin, Cout,
                                   mi_dtype(dy.dtype), _stream()), "convt2x2_dgrad")
