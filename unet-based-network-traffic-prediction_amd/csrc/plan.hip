@@ -532,7 +532,9 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
     for (const auto& l : P->layers) {
       if (l.kind != K_CONV3 && l.kind != K_CONVT) continue;
       if (J.n == kMaxPackJobs) { RUN(launch_pack_multi(J, dt, r.s)); J.n = 0; }
-      pack_jobs_add(J, r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.kind == K_CONVT, l.cout, l.cin, l.split);
+      if (!pack_jobs_add(J, r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.kind == K_CONVT, l.cout, l.cin,
+                         l.split))
+        return fail(MI_EINVAL, "unet_forward: layer too large to pack");
     }
     RUN(launch_pack_multi(J, dt, r.s));
   }

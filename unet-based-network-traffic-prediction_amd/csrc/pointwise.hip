@@ -24,58 +24,86 @@ template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v
 
 // ------------------------------------------------------------------------------------------
 // Layout: fp32 NCHW <-> NHWC view
-template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
-                                    int64_t npix, int C, int Cp, int HW) {
-  // one thread per (pixel, block of 32 channels): consecutive threads walk pixels, so every
-  // channel-plane read is coalesced, and a thread writes its pixel's 32 channels as whole
-  // 16-byte pieces of one contiguous row segment.
-  const int blocks = (Cp + 31) / 32;
-  const int64_t total = npix * blocks;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = i % npix;
-    const int c0 = (int)(i / npix) * 32;
-    const int64_t b = p / HW, r = p % HW;
-    const float* sp = src + (b * C + c0) * HW + r;
-    float v[32];
+// One thread per (pixel, block of 32 channels): consecutive threads walk pixels, so every
+// channel-plane read is coalesced, and a thread writes its pixel's 32 channels as whole 16-byte
+// pieces of one contiguous row segment.  NG = 4-channel groups of the block that hold real
+// channels; all their loads are issued unconditionally (channel index clamped) before any use.
+// Index math is 32-bit (64-bit division is emulated); the launcher checks the range.
+template <typename T, int NG>
+__device__ __forceinline__ void nchw_to_nhwc_block(const float* __restrict__ sp, T* __restrict__ dp, int nreal, int nstore,
+                                                   uint32_t HW) {
+  float v[NG * 4];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) v[q] = c0 + q < C ? sp[(int64_t)q * HW] : 0.f;
-    T* dp = dst + p * cs + co + c0;
+  for (int q = 0; q < NG * 4; ++q) v[q] = sp[(int64_t)(q < nreal ? q : nreal - 1) * HW];
 #pragma unroll
-    for (int q = 0; q < 32; q += 4)
-      if (c0 + q < Cp) store4f(dp + q, f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]});
-  }
+  for (int q = 0; q < NG * 4; ++q) v[q] = q < nreal ? v[q] : 0.f;
+  // the padded width covers every group that holds a real channel: these stores are unconditional
+#pragma unroll
+  for (int q = 0; q < NG * 4; q += 4) store4f(dp + q, f32x4_t{v[q], v[q + 1], v[q + 2], v[q + 3]});
+#pragma unroll
+  for (int q = NG * 4; q < 32; q += 4)
+    if (q < nstore) store4f(dp + q, f32x4_t{0.f, 0.f, 0.f, 0.f});
 }
 template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
+                                    uint32_t npix, int C, int Cp, uint32_t HW) {
+  const uint32_t blocks = (Cp + 31) / 32;
+  const uint32_t total = npix * blocks;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t cb = i / npix, p = i - cb * npix;
+    const int c0 = (int)cb * 32;
+    const uint32_t b = p / HW, r = p - b * HW;
+    const float* sp = src + ((int64_t)b * C + c0) * HW + r;
+    T* dp = dst + (int64_t)p * cs + co + c0;
+    const int nreal = min(32, C - c0), nstore = min(32, Cp - c0);   // nreal >= 1: pad_ch never adds a whole block
+    switch ((nreal + 3) / 4) {
+      case 1: nchw_to_nhwc_block<T, 1>(sp, dp, nreal, nstore, HW); break;
+      case 2: nchw_to_nhwc_block<T, 2>(sp, dp, nreal, nstore, HW); break;
+      case 3: nchw_to_nhwc_block<T, 3>(sp, dp, nreal, nstore, HW); break;
+      case 4: nchw_to_nhwc_block<T, 4>(sp, dp, nreal, nstore, HW); break;
+      case 5: nchw_to_nhwc_block<T, 5>(sp, dp, nreal, nstore, HW); break;
+      case 6: nchw_to_nhwc_block<T, 6>(sp, dp, nreal, nstore, HW); break;
+      case 7: nchw_to_nhwc_block<T, 7>(sp, dp, nreal, nstore, HW); break;
+      default: nchw_to_nhwc_block<T, 8>(sp, dp, nreal, nstore, HW); break;
+    }
+  }
+}
+template <typename T, typename I>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int cs, int co, float* __restrict__ dst,
-                                    int64_t npix, int C, int HW) {
-  const int64_t total = npix * C;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = i % npix;
-    const int c = (int)(i / npix);
-    const int64_t b = p / HW, r = p % HW;
-    dst[(b * C + c) * HW + r] = to_f(src[p * cs + co + c]);
+                                    I npix, int C, I HW) {
+  const I total = npix * (I)C;
+  for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I c = i / npix, p = i - c * npix;
+    const I b = p / HW, r = p - b * HW;
+    dst[((int64_t)b * C + c) * HW + r] = to_f(src[(int64_t)p * cs + co + c]);
   }
 }
 int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype,
                         hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
   const int Cp = pad_ch(C);
-  const int grid = grid_for(npix * ((Cp + 31) / 32), 256, 256 * 16);
+  const int64_t total = npix * ((Cp + 31) / 32);
+  MI_REQUIRE(total < (1ll << 31), "nchw_to_nhwc: tensor too large");
+  const int grid = grid_for(total, 256, 256 * 16);
   if (dtype == MI_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, npix, C, Cp, H * W);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, (uint32_t)npix, C, Cp, (uint32_t)(H * W));
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, npix, C, Cp, H * W);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, (uint32_t)npix, C, Cp, (uint32_t)(H * W));
   return check_hip(hipGetLastError(), "nchw_to_nhwc");
 }
 int launch_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W, int dtype,
                         hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
-  const int grid = grid_for(npix * C);
-  if (dtype == MI_BF16)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, cs, co, dst, npix, C, H * W);
-  else
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, cs, co, dst, npix, C, H * W);
+  const int64_t total = npix * C;
+  const int grid = grid_for(total, 256, 256 * 16);
+  const bool small = total < (1ll << 31);
+  if (dtype == MI_BF16) {
+    if (small) hipLaunchKernelGGL((nhwc_to_nchw_kernel<__bf16, uint32_t>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, cs, co, dst, (uint32_t)npix, C, (uint32_t)(H * W));
+    else hipLaunchKernelGGL((nhwc_to_nchw_kernel<__bf16, int64_t>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, cs, co, dst, npix, C, (int64_t)H * W);
+  } else {
+    if (small) hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, uint32_t>), dim3(grid), dim3(256), 0, s, (const float*)src, cs, co, dst, (uint32_t)npix, C, (uint32_t)(H * W));
+    else hipLaunchKernelGGL((nhwc_to_nchw_kernel<float, int64_t>), dim3(grid), dim3(256), 0, s, (const float*)src, cs, co, dst, npix, C, (int64_t)H * W);
+  }
   return check_hip(hipGetLastError(), "nhwc_to_nchw");
 }
 
@@ -91,64 +119,74 @@ __device__ __forceinline__ int unpos(int pos, int Cin, int split, int split_pad)
   }
   return pos < Cin ? pos : -1;
 }
+// Element -> source index.  The packers first compute the source index of each of a thread's
+// elements (-1 = padding), then issue all loads unconditionally with the index clamped to 0,
+// and only then select and store: a load inside a branch is waited for inside that branch,
+// which would serialise a thread's loads.
+// (element indices are 32-bit: 64-bit integer division is emulated and would dominate the kernel)
+__device__ __forceinline__ int64_t pack_conv3x3_src(int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2,
+                                                    uint32_t i, uint32_t nf) {
+  const int split_pad = pad_ch(split);
+  if (i < nf) {
+    const uint32_t n = i / (uint32_t)Kp, k = i - n * (uint32_t)Kp;
+    const uint32_t tap = k / (uint32_t)Cp, pos = k - tap * (uint32_t)Cp;
+    if ((int)n >= Cout || tap >= 9u) return -1;
+    const int ci = unpos((int)pos, Cin, split, split_pad);
+    return ci >= 0 ? ((int64_t)n * Cin + ci) * 9 + tap : -1;
+  }
+  const uint32_t j = i - nf;
+  const uint32_t pos = j / (uint32_t)Kp2, k = j - pos * (uint32_t)Kp2;
+  const uint32_t tap = k / (uint32_t)Np, co = k - tap * (uint32_t)Np;
+  if (tap >= 9u || (int)co >= Cout) return -1;
+  const int ci = unpos((int)pos, Cin, split, split_pad);
+  return ci >= 0 ? ((int64_t)co * Cin + ci) * 9 + (8 - tap) : -1;
+}
+__device__ __forceinline__ int64_t pack_convt2x2_src(int Cin, int Cout, int Np, int Cp, int Kp, int Kp2, uint32_t i,
+                                                     uint32_t nf) {
+  if (i < nf) {
+    const uint32_t row = i / (uint32_t)Kp, ci = i - row * (uint32_t)Kp;
+    const uint32_t g = row / (uint32_t)Np, co = row - g * (uint32_t)Np;
+    return ((int)co < Cout && (int)ci < Cin) ? ((int64_t)ci * Cout + co) * 4 + g : -1;
+  }
+  const uint32_t j = i - nf;
+  const uint32_t ci = j / (uint32_t)Kp2, k = j - ci * (uint32_t)Kp2;
+  const uint32_t g = k / (uint32_t)Np, co = k - g * (uint32_t)Np;
+  return ((int)ci < Cin && g < 4u && (int)co < Cout) ? ((int64_t)ci * Cout + co) * 4 + g : -1;
+}
+template <typename T>
+__device__ __forceinline__ void pack_store(T* __restrict__ wf, T* __restrict__ wb, uint32_t i, uint32_t nf, float v) {
+  if (i < nf) wf[i] = from_f<T>(v);
+  else wb[i - nf] = from_f<T>(v);
+}
 template <typename T>
 __device__ __forceinline__ void pack_conv3x3_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
                                                   int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2,
-                                                  int64_t i, int64_t nf) {
-  const int split_pad = pad_ch(split);
-  if (i < nf) {
-    const int n = (int)(i / Kp), k = (int)(i % Kp);
-    const int tap = k / Cp, pos = k % Cp;
-    float v = 0.f;
-    if (n < Cout && tap < 9) {
-      const int ci = unpos(pos, Cin, split, split_pad);
-      if (ci >= 0) v = w[((int64_t)n * Cin + ci) * 9 + tap];
-    }
-    wf[i] = from_f<T>(v);
-  } else {
-    const int64_t j = i - nf;
-    const int pos = (int)(j / Kp2), k = (int)(j % Kp2);
-    const int tap = k / Np, co = k % Np;
-    float v = 0.f;
-    if (tap < 9 && co < Cout) {
-      const int ci = unpos(pos, Cin, split, split_pad);
-      if (ci >= 0) v = w[((int64_t)co * Cin + ci) * 9 + (8 - tap)];
-    }
-    wb[j] = from_f<T>(v);
-  }
+                                                  uint32_t i, uint32_t nf) {
+  const int64_t src = pack_conv3x3_src(Cout, Cin, split, Np, Cp, Kp, Kp2, i, nf);
+  const float v = w[src >= 0 ? src : 0];
+  pack_store<T>(wf, wb, i, nf, src >= 0 ? v : 0.f);
 }
 template <typename T>
 __device__ __forceinline__ void pack_convt2x2_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
-                                                   int Cin, int Cout, int Np, int Cp, int Kp, int Kp2, int64_t i,
-                                                   int64_t nf) {
-  if (i < nf) {
-    const int row = (int)(i / Kp), ci = (int)(i % Kp);
-    const int g = row / Np, co = row % Np;
-    float v = 0.f;
-    if (co < Cout && ci < Cin) v = w[((int64_t)ci * Cout + co) * 4 + g];
-    wf[i] = from_f<T>(v);
-  } else {
-    const int64_t j = i - nf;
-    const int ci = (int)(j / Kp2), k = (int)(j % Kp2);
-    const int g = k / Np, co = k % Np;
-    float v = 0.f;
-    if (ci < Cin && g < 4 && co < Cout) v = w[((int64_t)ci * Cout + co) * 4 + g];
-    wb[j] = from_f<T>(v);
-  }
+                                                   int Cin, int Cout, int Np, int Cp, int Kp, int Kp2, uint32_t i,
+                                                   uint32_t nf) {
+  const int64_t src = pack_convt2x2_src(Cin, Cout, Np, Cp, Kp, Kp2, i, nf);
+  const float v = w[src >= 0 ? src : 0];
+  pack_store<T>(wf, wb, i, nf, src >= 0 ? v : 0.f);
 }
 template <typename T>
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
                                     int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2) {
   const int64_t nf = wf ? (int64_t)Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x)
-    pack_conv3x3_elem<T>(w, wf, wb, Cout, Cin, split, Np, Cp, Kp, Kp2, i, nf);
+    pack_conv3x3_elem<T>(w, wf, wb, Cout, Cin, split, Np, Cp, Kp, Kp2, (uint32_t)i, (uint32_t)nf);
 }
 template <typename T>
 __global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
                                      int Cin, int Cout, int Np, int Cp, int Kp, int Kp2) {
   const int64_t nf = wf ? (int64_t)4 * Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x)
-    pack_convt2x2_elem<T>(w, wf, wb, Cin, Cout, Np, Cp, Kp, Kp2, i, nf);
+    pack_convt2x2_elem<T>(w, wf, wb, Cin, Cout, Np, Cp, Kp, Kp2, (uint32_t)i, (uint32_t)nf);
 }
 // All layers of a network in one launch: the job table travels in the kernel arguments, a
 // workgroup finds its job from the running chunk counts (1024 packed elements per chunk).
@@ -159,23 +197,27 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs J) {
   while (j < J.n - 1 && chunk >= J.job[j].chunk_end) ++j;
   const PackJob& q = J.job[j];
   const int c0 = j > 0 ? J.job[j - 1].chunk_end : 0;
-  const int64_t base = (int64_t)(chunk - c0) * 1024 + threadIdx.x;
+  const uint32_t base = (uint32_t)(chunk - c0) * 1024u + threadIdx.x;
   T* wf = (T*)q.wf;
   T* wb = (T*)q.wb;
-  if (q.convt) {
-    const int64_t nf = wf ? (int64_t)4 * q.Np * q.Kp : 0, nb = wb ? (int64_t)q.Cp * q.Kp2 : 0;
+  const uint32_t nf = q.convt ? (wf ? 4u * q.Np * q.Kp : 0u) : (wf ? (uint32_t)q.Np * q.Kp : 0u);
+  const uint32_t nb = wb ? (uint32_t)q.Cp * q.Kp2 : 0u;
+  int64_t src[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t i = base + e * 256;
-      if (i < nf + nb) pack_convt2x2_elem<T>(q.w, wf, wb, q.Cin, q.Cout, q.Np, q.Cp, q.Kp, q.Kp2, i, nf);
-    }
-  } else {
-    const int64_t nf = wf ? (int64_t)q.Np * q.Kp : 0, nb = wb ? (int64_t)q.Cp * q.Kp2 : 0;
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t i = base + e * 256;
+    src[e] = -1;
+    if (i < nf + nb)
+      src[e] = q.convt ? pack_convt2x2_src(q.Cin, q.Cout, q.Np, q.Cp, q.Kp, q.Kp2, i, nf)
+                       : pack_conv3x3_src(q.Cout, q.Cin, q.split, q.Np, q.Cp, q.Kp, q.Kp2, i, nf);
+  }
+  float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t i = base + e * 256;
-      if (i < nf + nb) pack_conv3x3_elem<T>(q.w, wf, wb, q.Cout, q.Cin, q.split, q.Np, q.Cp, q.Kp, q.Kp2, i, nf);
-    }
+  for (int e = 0; e < 4; ++e) v[e] = q.w[src[e] >= 0 ? src[e] : 0];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t i = base + e * 256;
+    if (i < nf + nb) pack_store<T>(wf, wb, i, nf, src[e] >= 0 ? v[e] : 0.f);
   }
 }
 int pack_jobs_add(PackJobs& J, const float* w, void* wfwd, void* wbwd, int convt, int Cout, int Cin, int split) {
@@ -190,6 +232,7 @@ int pack_jobs_add(PackJobs& J, const float* w, void* wfwd, void* wbwd, int convt
     q.Np = pad_ch(Cout); q.Cp = concat_cp(Cin, split); q.Kp = (int)kpad(9 * q.Cp); q.Kp2 = (int)kpad(9 * q.Np);
     total = (wfwd ? (int64_t)q.Np * q.Kp : 0) + (wbwd ? (int64_t)q.Cp * q.Kp2 : 0);
   }
+  if (total >= (1ll << 31)) return 0;
   const int prev = J.n > 0 ? J.job[J.n - 1].chunk_end : 0;
   q.chunk_end = prev + (int)((total + 1023) / 1024);
   ++J.n;
@@ -210,6 +253,7 @@ int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Ci
   const int Kp = (int)kpad(9 * Cp), Kp2 = (int)kpad(9 * Np);
   const int64_t total = (wfwd ? (int64_t)Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
   if (total == 0) return MI_OK;
+  MI_REQUIRE(total < (1ll << 31), "pack_conv3x3: layer too large");
   const int grid = grid_for(total);
   if (dtype == MI_BF16)
     hipLaunchKernelGGL(pack_conv3x3_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)wfwd, (__bf16*)wbwd, Cout, Cin, split, Np, Cp, Kp, Kp2);
@@ -222,6 +266,7 @@ int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Co
   const int Kp = (int)kpad(Cp), Kp2 = (int)kpad(4 * Np);
   const int64_t total = (wfwd ? (int64_t)4 * Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
   if (total == 0) return MI_OK;
+  MI_REQUIRE(total < (1ll << 31), "pack_convt2x2: layer too large");
   const int grid = grid_for(total);
   if (dtype == MI_BF16)
     hipLaunchKernelGGL(pack_convt2x2_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)wfwd, (__bf16*)wbwd, Cin, Cout, Np, Cp, Kp, Kp2);
@@ -231,23 +276,50 @@ int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Co
 }
 
 // ------------------------------------------------------------------------------------------
-// 2x2 max-pool.  One thread per (output pixel, 4-channel group).
-template <typename T>
+// 2x2 max-pool.  One thread per (window, 16-byte channel group): 8 bf16 or 4 fp32 channels.
+// The index type I is 32-bit whenever the window count allows (64-bit division is emulated).
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float* v) {
+    const f32x4_t t = *(const f32x4_t*)p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = t[q];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) { *(f32x4_t*)p = f32x4_t{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Vec16<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const __bf16* p, float* v) {
+    const bf16x8_t t = *(const bf16x8_t*)p;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (float)t[q];
+  }
+  static __device__ __forceinline__ void store(__bf16* p, const float* v) {
+    bf16x8_t t;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = (__bf16)v[q];
+    *(bf16x8_t*)p = t;
+  }
+};
+template <typename T, typename I>
 __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xcs, int xco, T* __restrict__ y, int ycs,
                                     int yco, int B, int H, int W, int Cp) {
-  const int Ho = H / 2, Wo = W / 2, G = Cp / 4;
-  const int64_t total = (int64_t)B * Ho * Wo * G;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int g = (int)(i % G);
-    const int64_t op = i / G;
-    const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho);
-    const int64_t b = op / ((int64_t)Wo * Ho);
-    const T* px = x + ((b * H + 2 * oy) * W + 2 * ox) * (int64_t)xcs + xco + g * 4;
-    const f32x4_t v00 = load4f(px), v01 = load4f(px + xcs), v10 = load4f(px + (int64_t)W * xcs),
-                  v11 = load4f(px + (int64_t)(W + 1) * xcs);
-    f32x4_t m;
+  constexpr int N = Vec16<T>::N;
+  const I Ho = H / 2, Wo = W / 2, G = Cp / N;
+  const I total = (I)B * Ho * Wo * G;
+  for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I op = i / G, g = i - op * G;
+    const I t1 = op / Wo, ox = op - t1 * Wo;
+    const I b = t1 / Ho, oy = t1 - b * Ho;
+    const T* px = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * (int64_t)xcs + xco + g * N;
+    float v00[N], v01[N], v10[N], v11[N], m[N];
+    Vec16<T>::load(px, v00);
+    Vec16<T>::load(px + xcs, v01);
+    Vec16<T>::load(px + (int64_t)W * xcs, v10);
+    Vec16<T>::load(px + (int64_t)(W + 1) * xcs, v11);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < N; ++q) {
       // PyTorch's update rule: take val if (val > max) or isnan(val), scanning row-major.
       float mx = v00[q];
       if (v01[q] > mx || v01[q] != v01[q]) mx = v01[q];
@@ -255,37 +327,50 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xcs, int xco, T
       if (v11[q] > mx || v11[q] != v11[q]) mx = v11[q];
       m[q] = mx;
     }
-    store4f(y + op * ycs + yco + g * 4, m);
+    Vec16<T>::store(y + (int64_t)op * ycs + yco + g * N, m);
   }
 }
-// One thread per (2x2 window incl. the partial windows of odd sizes, 4-channel group).
-template <typename T>
+// Backward: the gradient of a pooled value goes to the FIRST maximum of its window (row-major
+// scan, PyTorch's rule); optionally adds the skip gradient already stored for the unpooled
+// tensor and applies the ReLU mask of x.  EVEN: H and W even, so every window is complete and
+// all loads are unconditional; otherwise the partial windows of the last row/column are
+// handled too (they only pass the skip gradient through).
+template <typename T, typename I, bool EVEN, bool SKIP>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dyp,
                                     int pcs, int pco, const T* __restrict__ dskip, int scs, int sco,
                                     T* __restrict__ dx, int dcs, int dco, int B, int H, int W, int Cp,
                                     int relu_mask) {
-  const int Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2, G = Cp / 4;
-  const int64_t total = (int64_t)B * Hc * Wc * G;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int g = (int)(i % G);
-    const int64_t wdx = i / G;
-    const int ox = (int)(wdx % Wc), oy = (int)((wdx / Wc) % Hc);
-    const int64_t b = wdx / ((int64_t)Wc * Hc);
-    const bool pooled = oy < Ho && ox < Wo;  // window produced a pooled output
-    f32x4_t xv[4], gv[4];
+  constexpr int N = Vec16<T>::N;
+  const I Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2, G = Cp / N;
+  const I total = (I)B * Hc * Wc * G;
+  for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
+    const I wdx = i / G, g = i - wdx * G;
+    const I t1 = wdx / Wc, ox = wdx - t1 * Wc;
+    const I b = t1 / Hc, oy = t1 - b * Hc;
+    const bool pooled = EVEN || (oy < Ho && ox < Wo);  // window produced a pooled output
+    float xv[4][N], gv[4][N];
     bool inb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
-      inb[k] = yy < H && xx < W;
-      const int64_t pix = (b * H + yy) * W + xx;
-      xv[k] = inb[k] ? load4f(x + pix * xcs + xco + g * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-      gv[k] = (inb[k] && dskip) ? load4f(dskip + pix * scs + sco + g * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const I yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+      inb[k] = EVEN || (yy < (I)H && xx < (I)W);
+      const int64_t pix = ((int64_t)b * H + yy) * W + xx;
+      if (inb[k]) Vec16<T>::load(x + pix * xcs + xco + g * N, xv[k]);
+      else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) xv[k][q] = 0.f;
+      }
+      if (inb[k] && SKIP) Vec16<T>::load(dskip + pix * scs + sco + g * N, gv[k]);
+      else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) gv[k][q] = 0.f;
+      }
     }
     if (pooled) {
-      const f32x4_t gp = load4f(dyp + ((b * Ho + oy) * (int64_t)Wo + ox) * pcs + pco + g * 4);
+      float gp[N];
+      Vec16<T>::load(dyp + (((int64_t)b * Ho + oy) * Wo + ox) * pcs + pco + g * N, gp);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < N; ++q) {
         int arg = 0;
         float mx = xv[0][q];
 #pragma unroll
@@ -298,85 +383,109 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xcs, int xco, c
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (!inb[k]) continue;
-      f32x4_t o = gv[k];
       if (relu_mask) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = xv[k][q] > 0.f ? o[q] : 0.f;
+        for (int q = 0; q < N; ++q) gv[k][q] = xv[k][q] > 0.f ? gv[k][q] : 0.f;
       }
-      const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
-      store4f(dx + ((b * H + yy) * W + xx) * (int64_t)dcs + dco + g * 4, o);
+      const I yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+      Vec16<T>::store(dx + (((int64_t)b * H + yy) * W + xx) * dcs + dco + g * N, gv[k]);
     }
   }
+}
+template <typename T>
+static void maxpool2_fwd_dispatch(int64_t total, hipStream_t s, const void* x, int xcs, int xco, void* y, int ycs, int yco,
+                                  int B, int H, int W, int Cp) {
+  const int grid = grid_for(total, 256, 256 * 16);
+  if (total < (1ll << 31))
+    hipLaunchKernelGGL((maxpool2_fwd_kernel<T, uint32_t>), dim3(grid), dim3(256), 0, s, (const T*)x, xcs, xco, (T*)y, ycs, yco, B, H, W, Cp);
+  else
+    hipLaunchKernelGGL((maxpool2_fwd_kernel<T, int64_t>), dim3(grid), dim3(256), 0, s, (const T*)x, xcs, xco, (T*)y, ycs, yco, B, H, W, Cp);
 }
 int launch_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C,
                         int dtype, hipStream_t s) {
   const int Cp = pad_ch(C);
-  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (Cp / 4);
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (Cp / (dtype == MI_BF16 ? 8 : 4));
   if (total == 0) return MI_OK;
-  const int grid = grid_for(total);
-  if (dtype == MI_BF16)
-    hipLaunchKernelGGL(maxpool2_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, (__bf16*)y, ycs, yco, B, H, W, Cp);
-  else
-    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, (float*)y, ycs, yco, B, H, W, Cp);
+  if (dtype == MI_BF16) maxpool2_fwd_dispatch<__bf16>(total, s, x, xcs, xco, y, ycs, yco, B, H, W, Cp);
+  else maxpool2_fwd_dispatch<float>(total, s, x, xcs, xco, y, ycs, yco, B, H, W, Cp);
   return check_hip(hipGetLastError(), "maxpool2_fwd");
+}
+template <typename T, typename I>
+static void maxpool2_bwd_dispatch2(bool even, int grid, hipStream_t s, const void* x, int xcs, int xco, const void* dyp,
+                                   int pcs, int pco, const void* dskip, int scs, int sco, void* dx, int dcs, int dco,
+                                   int B, int H, int W, int Cp, int relu_mask) {
+#define POOL_BWD(EV, SK)                                                                                               \
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<T, I, EV, SK>), dim3(grid), dim3(256), 0, s, (const T*)x, xcs, xco, (const T*)dyp, \
+                     pcs, pco, (const T*)dskip, scs, sco, (T*)dx, dcs, dco, B, H, W, Cp, relu_mask)
+  if (even && dskip) POOL_BWD(true, true);
+  else if (even) POOL_BWD(true, false);
+  else if (dskip) POOL_BWD(false, true);
+  else POOL_BWD(false, false);
+#undef POOL_BWD
 }
 int launch_maxpool2_bwd(const void* x, int xcs, int xco, const void* dyp, int pcs, int pco, const void* dskip,
                         int scs, int sco, void* dx, int dcs, int dco, int B, int H, int W, int C, int relu_mask,
                         int dtype, hipStream_t s) {
   const int Cp = pad_ch(C);
-  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (Cp / 4);
-  const int grid = grid_for(total);
-  if (dtype == MI_BF16)
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, (const __bf16*)dyp, pcs, pco, (const __bf16*)dskip, scs, sco, (__bf16*)dx, dcs, dco, B, H, W, Cp, relu_mask);
-  else
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, (const float*)dyp, pcs, pco, (const float*)dskip, scs, sco, (float*)dx, dcs, dco, B, H, W, Cp, relu_mask);
+  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (Cp / (dtype == MI_BF16 ? 8 : 4));
+  const int grid = grid_for(total, 256, 256 * 16);
+  const bool even = H % 2 == 0 && W % 2 == 0, small = total < (1ll << 31);
+  if (dtype == MI_BF16) {
+    if (small) maxpool2_bwd_dispatch2<__bf16, uint32_t>(even, grid, s, x, xcs, xco, dyp, pcs, pco, dskip, scs, sco, dx, dcs, dco, B, H, W, Cp, relu_mask);
+    else maxpool2_bwd_dispatch2<__bf16, int64_t>(even, grid, s, x, xcs, xco, dyp, pcs, pco, dskip, scs, sco, dx, dcs, dco, B, H, W, Cp, relu_mask);
+  } else {
+    if (small) maxpool2_bwd_dispatch2<float, uint32_t>(even, grid, s, x, xcs, xco, dyp, pcs, pco, dskip, scs, sco, dx, dcs, dco, B, H, W, Cp, relu_mask);
+    else maxpool2_bwd_dispatch2<float, int64_t>(even, grid, s, x, xcs, xco, dyp, pcs, pco, dskip, scs, sco, dx, dcs, dco, B, H, W, Cp, relu_mask);
+  }
   return check_hip(hipGetLastError(), "maxpool2_bwd");
 }
 
 // ------------------------------------------------------------------------------------------
 // 1x1 head.  Cout is tiny (1 or 12): a per-pixel dot product, bandwidth-bound.
 constexpr int kHeadMaxCin = 64, kHeadMaxCout = 16;
-template <typename T>
+template <typename T, int CP>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int xcs, int xco,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         float* __restrict__ pred, int64_t npix, int HW, int Cin,
-                                                        int Cp, int Cout) {
-  __shared__ float sw[kHeadMaxCout * kHeadMaxCin + kHeadMaxCout];
-  for (int i = threadIdx.x; i < Cout * Cp; i += blockDim.x) {
-    const int co = i / Cp, c = i % Cp;
+                                                        int Cout) {
+  __shared__ float sw[kHeadMaxCout * CP + kHeadMaxCout];
+  for (int i = threadIdx.x; i < Cout * CP; i += blockDim.x) {
+    const int co = i / CP, c = i % CP;
     sw[i] = c < Cin ? w[co * Cin + c] : 0.f;
   }
-  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * Cp + i] = bias[i];
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * CP + i] = bias[i];
   __syncthreads();
+  constexpr int N = Vec16<T>::N;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-    float acc[kHeadMaxCout];
-#pragma unroll
-    for (int co = 0; co < kHeadMaxCout; ++co) acc[co] = 0.f;
     const T* px = x + p * xcs + xco;
-    for (int c = 0; c < Cp; c += 4) {
-      const f32x4_t v = load4f(px + c);
+    float v[CP];                       // the whole pixel row first: all loads in flight together
 #pragma unroll
-      for (int co = 0; co < kHeadMaxCout; ++co)
-        if (co < Cout) {
+    for (int c = 0; c < CP; c += N) Vec16<T>::load(px + c, v + c);
+    // pixel counts fit 32 bits (checked by the launcher); 64-bit division is emulated
+    const uint32_t b = (uint32_t)p / (uint32_t)HW, r = (uint32_t)p - b * (uint32_t)HW;
+    for (int co = 0; co < Cout; ++co) {
+      float acc = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[co] = fmaf(v[q], sw[co * Cp + c + q], acc[co]);
-        }
+      for (int c = 0; c < CP; ++c) acc = fmaf(v[c], sw[co * CP + c], acc);
+      pred[((int64_t)b * Cout + co) * HW + r] = acc + sw[Cout * CP + co];
     }
-    const int64_t b = p / HW, r = p % HW;
-#pragma unroll
-    for (int co = 0; co < kHeadMaxCout; ++co)
-      if (co < Cout) pred[(b * Cout + co) * HW + r] = acc[co] + sw[Cout * Cp + co];
   }
 }
 int launch_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,
                     int W, int Cin, int Cout, int dtype, hipStream_t s) {
   MI_REQUIRE(pad_ch(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
   const int64_t npix = (int64_t)B * H * W;
-  const int grid = grid_for(npix);
-  if (dtype == MI_BF16)
-    hipLaunchKernelGGL(head_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad_ch(Cin), Cout);
-  else
-    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, pad_ch(Cin), Cout);
+  MI_REQUIRE(npix < (1ll << 31), "head: pixel count out of range");
+  const int grid = grid_for(npix, 256, 256 * 16);
+  const int Cp = pad_ch(Cin);
+#define HEAD_FWD(TT, CPV) \
+  hipLaunchKernelGGL((head_fwd_kernel<TT, CPV>), dim3(grid), dim3(256), 0, s, (const TT*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, Cout)
+  if (dtype == MI_BF16) {
+    if (Cp == 32) HEAD_FWD(__bf16, 32); else if (Cp == 48) HEAD_FWD(__bf16, 48); else HEAD_FWD(__bf16, 64);
+  } else {
+    if (Cp == 32) HEAD_FWD(float, 32); else if (Cp == 48) HEAD_FWD(float, 48); else HEAD_FWD(float, 64);
+  }
+#undef HEAD_FWD
   return check_hip(hipGetLastError(), "head_fwd");
 }
 
@@ -408,10 +517,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     const int64_t p = tile * kHeadTile + threadIdx.x;
     const bool ok = p < npix;
     float g[kHeadMaxCout];
-    const int64_t b = ok ? p / HW : 0, r = ok ? p % HW : 0;
+    const uint32_t b = ok ? (uint32_t)p / (uint32_t)HW : 0u, r = ok ? (uint32_t)p - b * (uint32_t)HW : 0u;
 #pragma unroll
     for (int co = 0; co < kHeadMaxCout; ++co) {
-      g[co] = (ok && co < Cout) ? dpred[(b * Cout + co) * HW + r] : 0.f;
+      g[co] = (ok && co < Cout) ? dpred[((int64_t)b * Cout + co) * HW + r] : 0.f;
       if (co < Cout) sg[threadIdx.x * Cout + co] = g[co];
     }
     for (int c = 0; c < Cp; c += 4) {
@@ -477,26 +586,31 @@ __global__ __launch_bounds__(256) void head_bwd_small_kernel(const T* __restrict
     for (int c = 0; c < CP; ++c) acc[co][c] = 0.f;
   }
   for (int64_t p = blockIdx.x * 256ll + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
-    const int64_t b = p / HW, r = p % HW;
+    const uint32_t b = (uint32_t)p / (uint32_t)HW, r = (uint32_t)p - b * (uint32_t)HW;
     float g[COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) { g[co] = dpred[(b * COUT + co) * HW + r]; accb[co] += g[co]; }
+    for (int co = 0; co < COUT; ++co) { g[co] = dpred[((int64_t)b * COUT + co) * HW + r]; accb[co] += g[co]; }
+    constexpr int N = Vec16<T>::N;
+    float xv[CP];                      // the whole pixel row first: all loads in flight together
 #pragma unroll
-    for (int c = 0; c < CP; c += 4) {
-      const f32x4_t xv = load4f(x + p * xcs + xco + c);
-      f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < CP; c += N) Vec16<T>::load(x + p * xcs + xco + c, xv + c);
+#pragma unroll
+    for (int c = 0; c < CP; c += N) {
+      float d[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) d[q] = 0.f;
 #pragma unroll
       for (int co = 0; co < COUT; ++co)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < N; ++q) {
           d[q] = fmaf(g[co], sw[co * CP + c + q], d[q]);
-          acc[co][c + q] = fmaf(g[co], xv[q], acc[co][c + q]);
+          acc[co][c + q] = fmaf(g[co], xv[c + q], acc[co][c + q]);
         }
       if (relu_mask) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = xv[q] > 0.f ? d[q] : 0.f;
+        for (int q = 0; q < N; ++q) d[q] = xv[c + q] > 0.f ? d[q] : 0.f;
       }
-      store4f(dx + p * dcs + dco + c, d);
+      Vec16<T>::store(dx + p * dcs + dco + c, d);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,20 +659,19 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
   if (ws_bytes < head_ws_bytes(Cin, Cout)) return fail(MI_ESIZE, "head_bwd: workspace too small");
   const int Cp = pad_ch(Cin);
   const int64_t npix = (int64_t)B * H * W;
+  MI_REQUIRE(npix < (1ll << 31), "head: pixel count out of range");
   const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
   const int nblocks = (int)(ntiles < kHeadBlocks ? ntiles : kHeadBlocks);
-  if (Cout <= 2 && (Cp == 32 || Cp == 16)) {
+  if (Cout <= 2 && Cp == 32) {
     int nb = (int)((npix + 255) / 256);
     if (nb > kHeadBlocks) nb = kHeadBlocks;
 #define HEAD_SMALL(TT, CO, CPV)                                                                                   \
     hipLaunchKernelGGL((head_bwd_small_kernel<TT, CO, CPV>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred, \
                        (TT*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, relu_mask)
     if (dtype == MI_BF16) {
-      if (Cout == 1 && Cp == 32) HEAD_SMALL(__bf16, 1, 32); else if (Cout == 1) HEAD_SMALL(__bf16, 1, 16);
-      else if (Cp == 32) HEAD_SMALL(__bf16, 2, 32); else HEAD_SMALL(__bf16, 2, 16);
+      if (Cout == 1) HEAD_SMALL(__bf16, 1, 32); else HEAD_SMALL(__bf16, 2, 32);
     } else {
-      if (Cout == 1 && Cp == 32) HEAD_SMALL(float, 1, 32); else if (Cout == 1) HEAD_SMALL(float, 1, 16);
-      else if (Cp == 32) HEAD_SMALL(float, 2, 32); else HEAD_SMALL(float, 2, 16);
+      if (Cout == 1) HEAD_SMALL(float, 1, 32); else HEAD_SMALL(float, 2, 32);
     }
 #undef HEAD_SMALL
     int rc2 = check_hip(hipGetLastError(), "head_bwd_small");
@@ -774,27 +887,31 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 
 // ------------------------------------------------------------------------------------------
 // Fixed-order combination of weight-gradient partials into the reference's parameter layout.
-// A 256-thread workgroup handles 64 consecutive partial columns; the split range is cut in 4
-// interleaved groups (one per wave) and each thread keeps 4 independent sums, so 16 loads per
-// output are in flight.  The combination order is fixed, hence bitwise repeatable.
-__device__ __forceinline__ float sum_splits4(const float* __restrict__ p, int64_t stride, int z0, int splits) {
+// A 256-thread workgroup handles 16 consecutive partial columns; the split range is cut in 16
+// interleaved groups (one per 16 threads) and each thread keeps 4 independent sums, so a layer
+// with few outputs and many splits still spreads over hundreds of workgroups with all its loads
+// in flight at once.  The combination order is fixed, hence bitwise repeatable.
+__device__ __forceinline__ float sum_splits16(const float* __restrict__ p, int64_t stride, int z0, int splits) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int z = z0;
-  for (; z + 12 < splits; z += 16) {
+  for (; z + 48 < splits; z += 64) {
     a0 += p[(int64_t)z * stride];
-    a1 += p[(int64_t)(z + 4) * stride];
-    a2 += p[(int64_t)(z + 8) * stride];
-    a3 += p[(int64_t)(z + 12) * stride];
+    a1 += p[(int64_t)(z + 16) * stride];
+    a2 += p[(int64_t)(z + 32) * stride];
+    a3 += p[(int64_t)(z + 48) * stride];
   }
-  for (; z < splits; z += 4) a0 += p[(int64_t)z * stride];
+  for (; z < splits; z += 16) a0 += p[(int64_t)z * stride];
   return (a0 + a1) + (a2 + a3);
 }
-__device__ __forceinline__ float combine4(float v, float* sh) {
-  // sh: [4][64]; returns the total in the threads of wave 0
+__device__ __forceinline__ float combine16(float v, float* sh) {
+  // sh: [16 groups][16 columns]; returns the total in threads 0..15
   sh[threadIdx.x] = v;
   __syncthreads();
-  const int o = threadIdx.x & 63;
-  return (sh[o] + sh[64 + o]) + (sh[128 + o] + sh[192 + o]);
+  const int o = threadIdx.x & 15;
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) s += sh[g * 16 + o];
+  return s;
 }
 __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum,
                                                               int splits, int Npad, int Cp, int Cout, int Cin, int split,
@@ -804,8 +921,8 @@ __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __rest
   const int K = 9 * Cp;
   const int split_pad = pad_ch(split);
   const int64_t total = (int64_t)Cout * K + Cout;
-  const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
-  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+  const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < total; base += (int64_t)gridDim.x * 16) {
     const int64_t i = base + o;
     float v = 0.f;
     int co = 0, k = 0;
@@ -813,13 +930,13 @@ __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __rest
     if (live) {
       if (is_w) {
         co = (int)(i / K); k = (int)(i % K);
-        v = sum_splits4(part + (int64_t)co * K + k, (int64_t)Npad * K, zg, splits);
+        v = sum_splits16(part + (int64_t)co * K + k, (int64_t)Npad * K, zg, splits);
       } else {
         co = (int)(i - (int64_t)Cout * K);
-        if (rowsum) v = sum_splits4(rowsum + co, Npad, zg, splits);
+        if (rowsum) v = sum_splits16(rowsum + co, Npad, zg, splits);
       }
     }
-    const float s = combine4(v, sh);
+    const float s = combine16(v, sh);
     if (zg == 0 && live) {
       if (is_w) {
         const int tap = k / Cp, pos = k % Cp;
@@ -842,8 +959,8 @@ __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __rest
   __shared__ float sh[256];
   const int K = 4 * Npad;
   const int64_t total = (int64_t)Cin * K + Cout;
-  const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
-  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+  const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < total; base += (int64_t)gridDim.x * 16) {
     const int64_t i = base + o;
     float v = 0.f;
     int ci = 0, k = 0;
@@ -851,13 +968,13 @@ __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __rest
     if (live) {
       if (is_w) {
         ci = (int)(i / K); k = (int)(i % K);
-        v = sum_splits4(part + (int64_t)ci * K + k, (int64_t)Cp_in * K, zg, splits);
+        v = sum_splits16(part + (int64_t)ci * K + k, (int64_t)Cp_in * K, zg, splits);
       } else if (colsum) {
         const int co = (int)(i - (int64_t)Cin * K);
-        for (int g = 0; g < 4; ++g) v += sum_splits4(colsum + g * Npad + co, K, zg, splits);
+        for (int g = 0; g < 4; ++g) v += sum_splits16(colsum + g * Npad + co, K, zg, splits);
       }
     }
-    const float s = combine4(v, sh);
+    const float s = combine16(v, sh);
     if (zg == 0 && live) {
       if (is_w) {
         const int g = k / Npad, co = k % Npad;
@@ -918,14 +1035,14 @@ int launch_finalize_conv3(const float* part, const float* rowsum, int splits, in
     return check_hip(hipGetLastError(), "finalize_conv3");
   }
   const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
-  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, s, part, rowsum, splits, Npad,
+  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, part, rowsum, splits, Npad,
                      Cp, Cout, Cin, split, dW, db, alpha, beta);
   return check_hip(hipGetLastError(), "finalize_conv3");
 }
 int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin, int Cout,
                           float* dW, float* db, float alpha, float beta, hipStream_t s) {
   const int64_t total = (int64_t)Cin * 4 * Npad + Cout;
-  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, s, part, colsum, splits, Cp_in,
+  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, part, colsum, splits, Cp_in,
                      Npad, Cin, Cout, dW, db, alpha, beta);
   return check_hip(hipGetLastError(), "finalize_convt");
 }
