@@ -107,7 +107,7 @@ int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split) {
   const int64_t tiles = (int64_t)((Na + 63) / 64) * ((K + 63) / 64);
   // enough workgroups to fill 256 CUs twice over, few enough partials for a cheap combine
   int64_t splits = (512 + tiles - 1) / tiles;
-  if (splits > 64) splits = 64;
+  if (splits > 256) splits = 256;
   const int64_t max_splits = (M + PB - 1) / PB;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -135,11 +135,13 @@ int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Ci
                         hipStream_t s);
 int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, hipStream_t s);
 // Packing of many layers in one launch (the table is passed by value in the kernel arguments).
-constexpr int kMaxPackJobs = 40;
+constexpr int kMaxPackJobs = 32;
 struct PackJob {
   const float* w; void* wf; void* wb;    // wf / wb may be null (that image is not produced)
   int convt, Cout, Cin, split, Np, Cp, Kp, Kp2;
   int chunk_end;                         // running count of 1024-element chunks up to and including this job
+  uint32_t mKp, mCp, mKp2, mNp;          // fast-division multipliers of Kp, Cp, Kp2, Np (shift 31 + s*)
+  uint8_t sKp, sCp, sKp2, sNp;
 };
 struct PackJobs { int n; PackJob job[kMaxPackJobs]; };
 int pack_jobs_add(PackJobs& J, const float* w, void* wfwd, void* wbwd, int convt, int Cout, int Cin, int split);

@@ -12,6 +12,8 @@
 //     addresses per pixel tile (tx = 0,1,2) plus a uniform ty offset -- no per-tap address math.
 //   * 512 threads = 8 waves = 2 per SIMD, each wave 2 pixel tiles x TN channel tiles: while
 //     one wave of a SIMD waits on LDS or issues loads/stores, its partner issues MFMAs.
+//     (4 waves of 4 pixel tiles each -- fewer LDS reads per MFMA -- measured 25% slower: with
+//     one wave per SIMD nothing covers that wave's LDS and global-load waits.)
 //   * workgroups are persistent over pixel tiles; when the layer has at most two channel
 //     chunks the packed weights of both stay resident in the two LDS stage buffers and are
 //     loaded once per workgroup.
@@ -39,12 +41,12 @@ struct HconvArgs {
 constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 64)
 constexpr int kHconvBigHalo = 768;      // 4x4 images (16 per tile, pitch 8): needs the narrower channel tiles
 
-template <typename T, int TN, int MH>
-__global__ __launch_bounds__(512, 2) void hconv_kernel(const HconvArgs a) {
+template <typename T, int TN, int MH, int TM>
+__global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const HconvArgs a) {
   typedef typename ElemTraits<T>::frag_t frag_t;
   constexpr int EPC = ElemTraits<T>::EPC;
   constexpr int CK = 4 * EPC;                    // channels per 64-byte chunk
-  constexpr int TM = 2, BM = 256, BN = TN * 16, NT = 512;
+  constexpr int BM = 256, BN = TN * 16, NT = BM / (TM * 16) * 64;
   constexpr int A_BYTES = MH * 64;
   constexpr int W_BYTES = 9 * BN * 64;
   constexpr int STAGE = A_BYTES + W_BYTES;
@@ -313,12 +315,12 @@ static int launch_hconv_t(const HconvArgs& a, hipStream_t s, const char** name) 
   if (gx > cap) gx = cap;
   dim3 grid(gx, ny);
   if (bighalo) {
-    if (bn == 32) { if (name) *name = "hconv_256x32_h768"; hipLaunchKernelGGL((hconv_kernel<T, 2, kHconvBigHalo>), grid, dim3(512), 0, s, a); }
-    else { if (name) *name = "hconv_256x16_h768"; hipLaunchKernelGGL((hconv_kernel<T, 1, kHconvBigHalo>), grid, dim3(512), 0, s, a); }
+    if (bn == 32) { if (name) *name = "hconv_256x32_h768"; hipLaunchKernelGGL((hconv_kernel<T, 2, kHconvBigHalo, 2>), grid, dim3(512), 0, s, a); }
+    else { if (name) *name = "hconv_256x16_h768"; hipLaunchKernelGGL((hconv_kernel<T, 1, kHconvBigHalo, 2>), grid, dim3(512), 0, s, a); }
   }
-  else if (bn == 64) { if (name) *name = "hconv_256x64"; hipLaunchKernelGGL((hconv_kernel<T, 4, kHconvMaxHalo>), grid, dim3(512), 0, s, a); }
-  else if (bn == 32) { if (name) *name = "hconv_256x32"; hipLaunchKernelGGL((hconv_kernel<T, 2, kHconvMaxHalo>), grid, dim3(512), 0, s, a); }
-  else { if (name) *name = "hconv_256x16"; hipLaunchKernelGGL((hconv_kernel<T, 1, kHconvMaxHalo>), grid, dim3(512), 0, s, a); }
+  else if (bn == 64) { if (name) *name = "hconv_256x64"; hipLaunchKernelGGL((hconv_kernel<T, 4, kHconvMaxHalo, 2>), grid, dim3(512), 0, s, a); }
+  else if (bn == 32) { if (name) *name = "hconv_256x32"; hipLaunchKernelGGL((hconv_kernel<T, 2, kHconvMaxHalo, 2>), grid, dim3(512), 0, s, a); }
+  else { if (name) *name = "hconv_256x16"; hipLaunchKernelGGL((hconv_kernel<T, 1, kHconvMaxHalo, 2>), grid, dim3(512), 0, s, a); }
   return check_hip(hipGetLastError(), "hconv launch");
 }
 

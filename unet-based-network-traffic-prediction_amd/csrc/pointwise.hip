@@ -124,33 +124,18 @@ __device__ __forceinline__ int unpos(int pos, int Cin, int split, int split_pad)
 // and only then select and store: a load inside a branch is waited for inside that branch,
 // which would serialise a thread's loads.
 // (element indices are 32-bit: 64-bit integer division is emulated and would dominate the kernel)
-__device__ __forceinline__ int64_t pack_conv3x3_src(int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2,
-                                                    uint32_t i, uint32_t nf) {
-  const int split_pad = pad_ch(split);
-  if (i < nf) {
-    const uint32_t n = i / (uint32_t)Kp, k = i - n * (uint32_t)Kp;
-    const uint32_t tap = k / (uint32_t)Cp, pos = k - tap * (uint32_t)Cp;
-    if ((int)n >= Cout || tap >= 9u) return -1;
-    const int ci = unpos((int)pos, Cin, split, split_pad);
-    return ci >= 0 ? ((int64_t)n * Cin + ci) * 9 + tap : -1;
-  }
-  const uint32_t j = i - nf;
-  const uint32_t pos = j / (uint32_t)Kp2, k = j - pos * (uint32_t)Kp2;
-  const uint32_t tap = k / (uint32_t)Np, co = k - tap * (uint32_t)Np;
-  if (tap >= 9u || (int)co >= Cout) return -1;
-  const int ci = unpos((int)pos, Cin, split, split_pad);
-  return ci >= 0 ? ((int64_t)co * Cin + ci) * 9 + (8 - tap) : -1;
-}
+struct PackDiv { FastDiv Kp, Cp, Kp2, Np; };
+__device__ __forceinline__ uint32_t pdiv(uint32_t n, const FastDiv& f) { return f.mul ? fdiv(n, f) : n / f.d; }
 __device__ __forceinline__ int64_t pack_convt2x2_src(int Cin, int Cout, int Np, int Cp, int Kp, int Kp2, uint32_t i,
-                                                     uint32_t nf) {
+                                                     uint32_t nf, const PackDiv& D) {
   if (i < nf) {
-    const uint32_t row = i / (uint32_t)Kp, ci = i - row * (uint32_t)Kp;
-    const uint32_t g = row / (uint32_t)Np, co = row - g * (uint32_t)Np;
+    const uint32_t row = pdiv(i, D.Kp), ci = i - row * (uint32_t)Kp;
+    const uint32_t g = pdiv(row, D.Np), co = row - g * (uint32_t)Np;
     return ((int)co < Cout && (int)ci < Cin) ? ((int64_t)ci * Cout + co) * 4 + g : -1;
   }
   const uint32_t j = i - nf;
-  const uint32_t ci = j / (uint32_t)Kp2, k = j - ci * (uint32_t)Kp2;
-  const uint32_t g = k / (uint32_t)Np, co = k - g * (uint32_t)Np;
+  const uint32_t ci = pdiv(j, D.Kp2), k = j - ci * (uint32_t)Kp2;
+  const uint32_t g = pdiv(k, D.Np), co = k - g * (uint32_t)Np;
   return ((int)ci < Cin && g < 4u && (int)co < Cout) ? ((int64_t)ci * Cout + co) * 4 + g : -1;
 }
 template <typename T>
@@ -158,38 +143,76 @@ __device__ __forceinline__ void pack_store(T* __restrict__ wf, T* __restrict__ w
   if (i < nf) wf[i] = from_f<T>(v);
   else wb[i - nf] = from_f<T>(v);
 }
-template <typename T>
-__device__ __forceinline__ void pack_conv3x3_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
-                                                  int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2,
-                                                  uint32_t i, uint32_t nf) {
-  const int64_t src = pack_conv3x3_src(Cout, Cin, split, Np, Cp, Kp, Kp2, i, nf);
-  const float v = w[src >= 0 ? src : 0];
-  pack_store<T>(wf, wb, i, nf, src >= 0 ? v : 0.f);
-}
-template <typename T>
-__device__ __forceinline__ void pack_convt2x2_elem(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
-                                                   int Cin, int Cout, int Np, int Cp, int Kp, int Kp2, uint32_t i,
-                                                   uint32_t nf) {
-  const int64_t src = pack_convt2x2_src(Cin, Cout, Np, Cp, Kp, Kp2, i, nf);
-  const float v = w[src >= 0 ? src : 0];
-  pack_store<T>(wf, wb, i, nf, src >= 0 ? v : 0.f);
-}
-template <typename T>
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
-                                    int Cout, int Cin, int split, int Np, int Cp, int Kp, int Kp2) {
-  const int64_t nf = wf ? (int64_t)Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x)
-    pack_conv3x3_elem<T>(w, wf, wb, Cout, Cin, split, Np, Cp, Kp, Kp2, (uint32_t)i, (uint32_t)nf);
-}
-template <typename T>
-__global__ void pack_convt2x2_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb,
-                                     int Cin, int Cout, int Np, int Cp, int Kp, int Kp2) {
-  const int64_t nf = wf ? (int64_t)4 * Np * Kp : 0, nb = wb ? (int64_t)Cp * Kp2 : 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * blockDim.x)
-    pack_convt2x2_elem<T>(w, wf, wb, Cin, Cout, Np, Cp, Kp, Kp2, (uint32_t)i, (uint32_t)nf);
-}
 // All layers of a network in one launch: the job table travels in the kernel arguments, a
-// workgroup finds its job from the running chunk counts (1024 packed elements per chunk).
+// workgroup finds its job from the running chunk counts.
+// 3x3 layers are packed by wave-sized units chosen so that a unit's sources form a compact run
+// of the (Cout,Cin,3,3) parameter: the 9 taps of a source line are consumed by the same wave
+// instead of by nine far-apart workgroups (each line would otherwise be fetched 9 times from L2).
+//   forward image  wf[n][tap*Cp + pos]:  unit = (row n, block of 128 positions), lanes along pos
+//   backward image wb[pos][tap*Np + co]: unit = (4 positions, 32 output channels), lanes along co
+// Transposed-conv layers are small and keep the flat element order (1024 elements per chunk).
+template <typename T>
+__device__ __forceinline__ void pack_conv3x3_unit(const PackJob& q, int unit, int lane) {
+  T* wf = (T*)q.wf;
+  T* wb = (T*)q.wb;
+  const int split_pad = pad_ch(q.split);
+  const int npb = (q.Cp + 127) / 128, ncb = (q.Np + 31) / 32, npq = (q.Cp + 3) / 4;
+  const int units_wf = wf ? q.Np * npb : 0, units_wb = wb ? npq * ncb : 0;
+  if (unit < units_wf) {
+    const int n = unit / npb, pb = unit - n * npb;
+    // 18 elements per lane in two batches of 9: all loads of a batch are in flight together
+    // (offsets are 32-bit: a layer has fewer than 2^31 packed elements)
+    for (int e0 = 0; e0 < 9 * 128; e0 += 576) {
+      int src[9], dst[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int e = e0 + k * 64 + lane;
+        const int tap = e >> 7, pos = pb * 128 + (e & 127);
+        src[k] = -1; dst[k] = -1;
+        if (pos < q.Cp) {
+          dst[k] = n * q.Kp + tap * q.Cp + pos;
+          const int ci = unpos(pos, q.Cin, q.split, split_pad);
+          if (n < q.Cout && ci >= 0) src[k] = (n * q.Cin + ci) * 9 + tap;
+        }
+      }
+      float v[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = q.w[src[k] >= 0 ? src[k] : 0];
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (dst[k] >= 0) wf[dst[k]] = from_f<T>(src[k] >= 0 ? v[k] : 0.f);
+    }
+    if (pb == 0 && lane < q.Kp - 9 * q.Cp) wf[(int64_t)n * q.Kp + 9 * q.Cp + lane] = from_f<T>(0.f);
+  } else if (unit < units_wf + units_wb) {
+    const int u = unit - units_wf;
+    const int pq = u / ncb, cb = u - pq * ncb;
+    const int co = cb * 32 + (lane & 31);
+    for (int r0 = 0; r0 < 36; r0 += 18) {         // r = 9*pl + tap, two r per 64-lane pass, 9 passes per batch
+      int src[9], dst[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int r = r0 + 2 * k + (lane >> 5);
+        const int pl = r / 9, tap = r - pl * 9, pos = pq * 4 + pl;
+        src[k] = -1; dst[k] = -1;
+        if (pos < q.Cp && co < q.Np) {
+          dst[k] = pos * q.Kp2 + tap * q.Np + co;
+          const int ci = unpos(pos, q.Cin, q.split, split_pad);
+          if (co < q.Cout && ci >= 0) src[k] = (co * q.Cin + ci) * 9 + (8 - tap);
+        }
+      }
+      float v[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = q.w[src[k] >= 0 ? src[k] : 0];
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (dst[k] >= 0) wb[dst[k]] = from_f<T>(src[k] >= 0 ? v[k] : 0.f);
+    }
+    if (cb == 0 && lane < q.Kp2 - 9 * q.Np) {
+      for (int pl = 0; pl < 4; ++pl)
+        if (pq * 4 + pl < q.Cp) wb[(int64_t)(pq * 4 + pl) * q.Kp2 + 9 * q.Np + lane] = from_f<T>(0.f);
+    }
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs J) {
   const int chunk = blockIdx.x;
@@ -197,19 +220,23 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs J) {
   while (j < J.n - 1 && chunk >= J.job[j].chunk_end) ++j;
   const PackJob& q = J.job[j];
   const int c0 = j > 0 ? J.job[j - 1].chunk_end : 0;
+  if (!q.convt) {
+    pack_conv3x3_unit<T>(q, (chunk - c0) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+    return;
+  }
   const uint32_t base = (uint32_t)(chunk - c0) * 1024u + threadIdx.x;
   T* wf = (T*)q.wf;
   T* wb = (T*)q.wb;
-  const uint32_t nf = q.convt ? (wf ? 4u * q.Np * q.Kp : 0u) : (wf ? (uint32_t)q.Np * q.Kp : 0u);
+  const uint32_t nf = wf ? 4u * q.Np * q.Kp : 0u;
   const uint32_t nb = wb ? (uint32_t)q.Cp * q.Kp2 : 0u;
+  const PackDiv D{{q.mKp, 31u + q.sKp, (uint32_t)q.Kp}, {q.mCp, 31u + q.sCp, (uint32_t)q.Cp},
+                  {q.mKp2, 31u + q.sKp2, (uint32_t)q.Kp2}, {q.mNp, 31u + q.sNp, (uint32_t)q.Np}};
   int64_t src[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const uint32_t i = base + e * 256;
     src[e] = -1;
-    if (i < nf + nb)
-      src[e] = q.convt ? pack_convt2x2_src(q.Cin, q.Cout, q.Np, q.Cp, q.Kp, q.Kp2, i, nf)
-                       : pack_conv3x3_src(q.Cout, q.Cin, q.split, q.Np, q.Cp, q.Kp, q.Kp2, i, nf);
+    if (i < nf + nb) src[e] = pack_convt2x2_src(q.Cin, q.Cout, q.Np, q.Cp, q.Kp, q.Kp2, i, nf, D);
   }
   float v[4];
 #pragma unroll
@@ -233,8 +260,17 @@ int pack_jobs_add(PackJobs& J, const float* w, void* wfwd, void* wbwd, int convt
     total = (wfwd ? (int64_t)q.Np * q.Kp : 0) + (wbwd ? (int64_t)q.Cp * q.Kp2 : 0);
   }
   if (total >= (1ll << 31)) return 0;
+  const FastDiv dKp = make_fastdiv(q.Kp), dCp = make_fastdiv(q.Cp), dKp2 = make_fastdiv(q.Kp2), dNp = make_fastdiv(q.Np);
+  q.mKp = dKp.mul; q.sKp = (uint8_t)(dKp.shift - 31); q.mCp = dCp.mul; q.sCp = (uint8_t)(dCp.shift - 31);
+  q.mKp2 = dKp2.mul; q.sKp2 = (uint8_t)(dKp2.shift - 31); q.mNp = dNp.mul; q.sNp = (uint8_t)(dNp.shift - 31);
   const int prev = J.n > 0 ? J.job[J.n - 1].chunk_end : 0;
-  q.chunk_end = prev + (int)((total + 1023) / 1024);
+  if (convt) {
+    q.chunk_end = prev + (int)((total + 1023) / 1024);
+  } else {   // wave-sized units, 4 per workgroup (see pack_conv3x3_unit)
+    const int64_t units = (wfwd ? (int64_t)q.Np * ((q.Cp + 127) / 128) : 0) +
+                          (wbwd ? (int64_t)((q.Cp + 3) / 4) * ((q.Np + 31) / 32) : 0);
+    q.chunk_end = prev + (int)((units + 3) / 4);
+  }
   ++J.n;
   return 1;
 }
@@ -249,30 +285,18 @@ int launch_pack_multi(const PackJobs& J, int dtype, hipStream_t s) {
 }
 int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype,
                         hipStream_t s) {
-  const int Np = pad_ch(Cout), Cp = concat_cp(Cin, split);
-  const int Kp = (int)kpad(9 * Cp), Kp2 = (int)kpad(9 * Np);
-  const int64_t total = (wfwd ? (int64_t)Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
-  if (total == 0) return MI_OK;
-  MI_REQUIRE(total < (1ll << 31), "pack_conv3x3: layer too large");
-  const int grid = grid_for(total);
-  if (dtype == MI_BF16)
-    hipLaunchKernelGGL(pack_conv3x3_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)wfwd, (__bf16*)wbwd, Cout, Cin, split, Np, Cp, Kp, Kp2);
-  else
-    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)wfwd, (float*)wbwd, Cout, Cin, split, Np, Cp, Kp, Kp2);
-  return check_hip(hipGetLastError(), "pack_conv3x3");
+  if (!wfwd && !wbwd) return MI_OK;
+  PackJobs J;
+  J.n = 0;
+  MI_REQUIRE(pack_jobs_add(J, w, wfwd, wbwd, 0, Cout, Cin, split), "pack_conv3x3: layer too large");
+  return launch_pack_multi(J, dtype, s);
 }
 int launch_pack_convt2x2(const float* w, void* wfwd, void* wbwd, int Cin, int Cout, int dtype, hipStream_t s) {
-  const int Np = pad_ch(Cout), Cp = pad_ch(Cin);
-  const int Kp = (int)kpad(Cp), Kp2 = (int)kpad(4 * Np);
-  const int64_t total = (wfwd ? (int64_t)4 * Np * Kp : 0) + (wbwd ? (int64_t)Cp * Kp2 : 0);
-  if (total == 0) return MI_OK;
-  MI_REQUIRE(total < (1ll << 31), "pack_convt2x2: layer too large");
-  const int grid = grid_for(total);
-  if (dtype == MI_BF16)
-    hipLaunchKernelGGL(pack_convt2x2_kernel<__bf16>, dim3(grid), dim3(256), 0, s, w, (__bf16*)wfwd, (__bf16*)wbwd, Cin, Cout, Np, Cp, Kp, Kp2);
-  else
-    hipLaunchKernelGGL(pack_convt2x2_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)wfwd, (float*)wbwd, Cin, Cout, Np, Cp, Kp, Kp2);
-  return check_hip(hipGetLastError(), "pack_convt2x2");
+  if (!wfwd && !wbwd) return MI_OK;
+  PackJobs J;
+  J.n = 0;
+  MI_REQUIRE(pack_jobs_add(J, w, wfwd, wbwd, 1, Cout, Cin, 0), "pack_convt2x2: layer too large");
+  return launch_pack_multi(J, dtype, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -887,42 +911,55 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 
 // ------------------------------------------------------------------------------------------
 // Fixed-order combination of weight-gradient partials into the reference's parameter layout.
-// A 256-thread workgroup handles 16 consecutive partial columns; the split range is cut in 16
-// interleaved groups (one per 16 threads) and each thread keeps 4 independent sums, so a layer
-// with few outputs and many splits still spreads over hundreds of workgroups with all its loads
-// in flight at once.  The combination order is fixed, hence bitwise repeatable.
-__device__ __forceinline__ float sum_splits16(const float* __restrict__ p, int64_t stride, int z0, int splits) {
+// A 256-thread workgroup handles 256/G consecutive partial columns; the split range is cut in G
+// interleaved groups (G = 1..16, a power of two chosen from the split count) and each thread
+// keeps 4 independent sums, so a layer with few outputs and many splits still spreads over
+// hundreds of workgroups with all its loads in flight at once, and a layer with few splits keeps
+// every thread busy.  The combination order is fixed, hence bitwise repeatable.
+__device__ __forceinline__ float sum_splits(const float* __restrict__ p, int64_t stride, int z0, int splits, int G) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int z = z0;
-  for (; z + 48 < splits; z += 64) {
-    a0 += p[(int64_t)z * stride];
-    a1 += p[(int64_t)(z + 16) * stride];
-    a2 += p[(int64_t)(z + 32) * stride];
-    a3 += p[(int64_t)(z + 48) * stride];
+  // 16 loads in flight per thread (the partials of other workgroups come from HBM / remote L2)
+  for (; z + 15 * G < splits; z += 16 * G) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = p[(int64_t)(z + k * G) * stride];
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) { a0 += v[k]; a1 += v[k + 1]; a2 += v[k + 2]; a3 += v[k + 3]; }
   }
-  for (; z < splits; z += 16) a0 += p[(int64_t)z * stride];
+  for (; z + 3 * G < splits; z += 4 * G) {
+    const float v0 = p[(int64_t)z * stride], v1 = p[(int64_t)(z + G) * stride], v2 = p[(int64_t)(z + 2 * G) * stride],
+                v3 = p[(int64_t)(z + 3 * G) * stride];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; z < splits; z += G) a0 += p[(int64_t)z * stride];
   return (a0 + a1) + (a2 + a3);
 }
-__device__ __forceinline__ float combine16(float v, float* sh) {
-  // sh: [16 groups][16 columns]; returns the total in threads 0..15
+__device__ __forceinline__ float combine_groups(float v, float* sh, int G, int cols) {
+  // sh: [G groups][cols columns]; returns the total in threads 0..cols-1
   sh[threadIdx.x] = v;
   __syncthreads();
-  const int o = threadIdx.x & 15;
+  const int o = threadIdx.x & (cols - 1);
   float s = 0.f;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) s += sh[g * 16 + o];
+  for (int g = 0; g < G; ++g) s += sh[g * cols + o];
   return s;
+}
+static inline int finalize_groups(int splits) {
+  int g = 1;
+  while (g < 16 && g < splits) g *= 2;
+  return g;
 }
 __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum,
                                                               int splits, int Npad, int Cp, int Cout, int Cin, int split,
                                                               float* __restrict__ dW, float* __restrict__ db, float alpha,
-                                                              float beta) {
+                                                              float beta, int G) {
   __shared__ float sh[256];
   const int K = 9 * Cp;
   const int split_pad = pad_ch(split);
   const int64_t total = (int64_t)Cout * K + Cout;
-  const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
-  for (int64_t base = (int64_t)blockIdx.x * 16; base < total; base += (int64_t)gridDim.x * 16) {
+  const int cols = 256 / G;
+  const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
+  for (int64_t base = (int64_t)blockIdx.x * cols; base < total; base += (int64_t)gridDim.x * cols) {
     const int64_t i = base + o;
     float v = 0.f;
     int co = 0, k = 0;
@@ -930,13 +967,13 @@ __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __rest
     if (live) {
       if (is_w) {
         co = (int)(i / K); k = (int)(i % K);
-        v = sum_splits16(part + (int64_t)co * K + k, (int64_t)Npad * K, zg, splits);
+        v = sum_splits(part + (int64_t)co * K + k, (int64_t)Npad * K, zg, splits, G);
       } else {
         co = (int)(i - (int64_t)Cout * K);
-        if (rowsum) v = sum_splits16(rowsum + co, Npad, zg, splits);
+        if (rowsum) v = sum_splits(rowsum + co, Npad, zg, splits, G);
       }
     }
-    const float s = combine16(v, sh);
+    const float s = combine_groups(v, sh, G, cols);
     if (zg == 0 && live) {
       if (is_w) {
         const int tap = k / Cp, pos = k % Cp;
@@ -955,12 +992,13 @@ __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __rest
 __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __restrict__ part, const float* __restrict__ colsum,
                                                               int splits, int Cp_in, int Npad, int Cin, int Cout,
                                                               float* __restrict__ dW, float* __restrict__ db, float alpha,
-                                                              float beta) {
+                                                              float beta, int G) {
   __shared__ float sh[256];
   const int K = 4 * Npad;
   const int64_t total = (int64_t)Cin * K + Cout;
-  const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
-  for (int64_t base = (int64_t)blockIdx.x * 16; base < total; base += (int64_t)gridDim.x * 16) {
+  const int cols = 256 / G;
+  const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
+  for (int64_t base = (int64_t)blockIdx.x * cols; base < total; base += (int64_t)gridDim.x * cols) {
     const int64_t i = base + o;
     float v = 0.f;
     int ci = 0, k = 0;
@@ -968,13 +1006,13 @@ __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __rest
     if (live) {
       if (is_w) {
         ci = (int)(i / K); k = (int)(i % K);
-        v = sum_splits16(part + (int64_t)ci * K + k, (int64_t)Cp_in * K, zg, splits);
+        v = sum_splits(part + (int64_t)ci * K + k, (int64_t)Cp_in * K, zg, splits, G);
       } else if (colsum) {
         const int co = (int)(i - (int64_t)Cin * K);
-        for (int g = 0; g < 4; ++g) v += sum_splits16(colsum + g * Npad + co, K, zg, splits);
+        for (int g = 0; g < 4; ++g) v += sum_splits(colsum + g * Npad + co, K, zg, splits, G);
       }
     }
-    const float s = combine16(v, sh);
+    const float s = combine_groups(v, sh, G, cols);
     if (zg == 0 && live) {
       if (is_w) {
         const int g = k / Npad, co = k % Npad;
@@ -1035,15 +1073,17 @@ int launch_finalize_conv3(const float* part, const float* rowsum, int splits, in
     return check_hip(hipGetLastError(), "finalize_conv3");
   }
   const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
-  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, part, rowsum, splits, Npad,
-                     Cp, Cout, Cin, split, dW, db, alpha, beta);
+  const int G = finalize_groups(splits);
+  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 256 / G, 8192)), dim3(256), 0, s, part, rowsum, splits, Npad,
+                     Cp, Cout, Cin, split, dW, db, alpha, beta, G);
   return check_hip(hipGetLastError(), "finalize_conv3");
 }
 int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin, int Cout,
                           float* dW, float* db, float alpha, float beta, hipStream_t s) {
   const int64_t total = (int64_t)Cin * 4 * Npad + Cout;
-  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, part, colsum, splits, Cp_in,
-                     Npad, Cin, Cout, dW, db, alpha, beta);
+  const int G = finalize_groups(splits);
+  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 256 / G, 8192)), dim3(256), 0, s, part, colsum, splits, Cp_in,
+                     Npad, Cin, Cout, dW, db, alpha, beta, G);
   return check_hip(hipGetLastError(), "finalize_convt");
 }
 
