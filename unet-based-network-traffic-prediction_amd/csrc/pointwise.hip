@@ -944,9 +944,10 @@ __device__ __forceinline__ float combine_groups(float v, float* sh, int G, int c
   for (int g = 0; g < G; ++g) s += sh[g * cols + o];
   return s;
 }
-static inline int finalize_groups(int splits) {
+static inline int finalize_groups(int splits, int64_t outputs) {
+  // as many split groups as it takes to reach ~2048 workgroups, at most 16 and at most the split count
   int g = 1;
-  while (g < 16 && g < splits) g *= 2;
+  while (g < 16 && g < splits && outputs * (2 * g) <= 2048ll * 256) g *= 2;
   return g;
 }
 __global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum,
@@ -1073,7 +1074,7 @@ int launch_finalize_conv3(const float* part, const float* rowsum, int splits, in
     return check_hip(hipGetLastError(), "finalize_conv3");
   }
   const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
-  const int G = finalize_groups(splits);
+  const int G = finalize_groups(splits, total);
   hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 256 / G, 8192)), dim3(256), 0, s, part, rowsum, splits, Npad,
                      Cp, Cout, Cin, split, dW, db, alpha, beta, G);
   return check_hip(hipGetLastError(), "finalize_conv3");
@@ -1081,7 +1082,7 @@ int launch_finalize_conv3(const float* part, const float* rowsum, int splits, in
 int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin, int Cout,
                           float* dW, float* db, float alpha, float beta, hipStream_t s) {
   const int64_t total = (int64_t)Cin * 4 * Npad + Cout;
-  const int G = finalize_groups(splits);
+  const int G = finalize_groups(splits, total);
   hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 256 / G, 8192)), dim3(256), 0, s, part, colsum, splits, Cp_in,
                      Npad, Cin, Cout, dW, db, alpha, beta, G);
   return check_hip(hipGetLastError(), "finalize_convt");
