@@ -116,8 +116,9 @@ def main():
     Y = unet_amd.shard_batch(Yg, rank, world).to(dev)
     del Xg, Yg
 
-    reducer = unet_amd.GradientReducer().attach(model) if world > 1 else None
-    if world > 1:
+    force_dp = os.environ.get("UNET_TM_FORCE_DP") == "1"      # one-rank rehearsal of the RCCL path
+    reducer = unet_amd.GradientReducer(force=force_dp).attach(model) if (world > 1 or force_dp) else None
+    if world > 1 or force_dp:
         model.flat_parameters()
         unet_amd.broadcast_parameters(model)
     if args.stock_optim:
@@ -231,4 +232,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

@@ -24,14 +24,24 @@ import torch
 import torch.distributed as dist
 
 
+_DEBUG = os.environ.get("UNET_TM_DEBUG_DP", "0") == "1"
+
+
 def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
     ``backend`` defaults to "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".
-    Returns (rank, world_size, local_rank)."""
+    Returns (rank, world_size, local_rank).
+
+    Rehearsal on a box with fewer GPUs than ranks: ``UNET_TM_DIST_BACKEND=gloo`` selects the
+    backend and ``UNET_TM_FORCE_DEVICE=<index>`` puts every rank on that one device (RCCL itself
+    refuses two ranks per GPU; gloo stages through host memory)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if "UNET_TM_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["UNET_TM_FORCE_DEVICE"])
+    backend = backend or os.environ.get("UNET_TM_DIST_BACKEND") or None
+    if (world > 1 or os.environ.get("UNET_TM_FORCE_DP") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -78,16 +88,19 @@ def plan_buckets(segments: List[Tuple[int, int]], bucket_bytes: int) -> List[Tup
 class GradientReducer:
     """Averages a flat gradient buffer across the process group, bucket by bucket."""
 
-    def __init__(self, process_group=None, bucket_bytes: int = 8 << 20):
+    def __init__(self, process_group=None, bucket_bytes: int = 8 << 20, force: bool = False):
+        """``force`` keeps the bucketed path (and its collectives) active in a one-rank group:
+        a way to exercise the RCCL calls on a single GPU."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()
         self.bucket_bytes = bucket_bytes
         self.grad_prescale = 1.0 / self.world
         self._pending = []
         self._bucket_cache = {}
 
     def attach(self, model) -> "GradientReducer":
-        model._dp = self if self.world > 1 else None
+        model._dp = self if (self.world > 1 or self.force) else None
         return self
 
     def buckets_for(self, plan) -> List[Tuple[int, int, int, int]]:
@@ -99,12 +112,16 @@ class GradientReducer:
         return b
 
     def reduce_async(self, flat_slice: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.world > 1 or self.force:
+            if _DEBUG:
+                print(f"[dp rank {dist.get_rank(self.group)}] all_reduce {flat_slice.numel()} elements", flush=True)
             self._pending.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait_all(self) -> None:
-        for w in self._pending:
+        for i, w in enumerate(self._pending):
             w.wait()
+            if _DEBUG:
+                print(f"[dp rank {dist.get_rank(self.group)}] bucket {i} done", flush=True)
         self._pending.clear()
 
     def reduce_flat(self, flat: torch.Tensor, segments: List[Tuple[int, int]], prescaled: bool = False) -> None:
