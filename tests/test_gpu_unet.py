@@ -7,6 +7,7 @@ bf16-autocast-vs-fp64 noise floors of this network:
   bf16 kernels : layer outputs <= 1e-2, gradients <= 5e-2 median / 1.5e-1 worst tensor,
                  20-step loss curve rel <= 2e-3
 """
+import os
 import types
 from collections import OrderedDict
 
@@ -274,3 +275,70 @@ def test_full_size_properties(ua, dtype):
     _, gb = grads(X[256:], Y[256:])
     assert rel(0.5 * (ga + gb), g1) < (2e-5 if dtype == "fp32" else 2e-2)
     assert torch.isfinite(g1).all()
+
+
+def test_bucketed_backward_matches_single_call():
+    """The data-parallel route runs backward bucket by bucket (several mi_unet_backward calls over
+    segment ranges, a collective started after each): same gradients, bit for bit, as one call."""
+    import unet_amd
+
+    class Recorder(unet_amd.GradientReducer):
+        def reduce_async(self, t):
+            self.calls.append(t.numel())
+
+        def wait_all(self):
+            pass
+
+    torch.manual_seed(0)
+    m = unet_amd.UNet(12, 1, (8, 16, 32, 64), compute_dtype="bf16").cuda()
+    X, Y = O.synthetic_batch(8, 12, 1, 32, 32)
+    X, Y = X.cuda(), Y.cuda()
+    crit = unet_amd.MSELoss()
+    crit(m(X), Y).backward()
+    g0 = [p.grad.clone() for p in m.parameters()]
+    red = Recorder(bucket_bytes=64 << 10)
+    red.calls, red.force = [], True
+    red.attach(m)
+    assert m._dp is red
+    for p in m.parameters():
+        p.grad = None
+    crit(m(X), Y).backward()
+    torch.cuda.synchronize()
+    assert len(red.calls) > 1 and sum(red.calls) >= sum(p.numel() for p in m.parameters())
+    for a, p in zip(g0, m.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+def test_one_rank_rccl_group_runs_the_collective_path():
+    """A one-rank RCCL group: the asynchronous all-reduces of the gradient buckets and the
+    stream hand-over to the optimizer run for real; the averaged gradient of one rank is its own."""
+    import torch.distributed as dist
+    import unet_amd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(0)
+        m = unet_amd.UNet(12, 1, (8, 16, 32, 64), compute_dtype="fp32").cuda()
+        X, Y = O.synthetic_batch(4, 12, 1, 16, 16)
+        X, Y = X.cuda(), Y.cuda()
+        crit = unet_amd.MSELoss()
+        crit(m(X), Y).backward()
+        g0 = [p.grad.clone() for p in m.parameters()]
+        unet_amd.GradientReducer(bucket_bytes=64 << 10, force=True).attach(m)
+        unet_amd.broadcast_parameters(m)
+        opt = unet_amd.FusedAdam(m.parameters(), lr=1e-4, model=m)
+        for _ in range(3):
+            loss = crit(m(X), Y)
+            opt.zero_grad()
+            loss.backward()
+            if _ == 0:
+                for a, p in zip(g0, m.parameters()):
+                    assert torch.equal(a, p.grad)
+            opt.step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).item()
+    finally:
+        dist.destroy_process_group()
