@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--layers-out", default="", help="write per-launch records of the last instrumented step here")
+    ap.add_argument("--bucket-mb", type=float, default=8.0, help="gradient all-reduce bucket size (MiB), N > 1 only")
     ap.add_argument("--stock-optim", action="store_true", help="torch.optim.Adam + nn.MSELoss instead of the fused ones")
     args = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
     del Xg, Yg
 
     force_dp = os.environ.get("UNET_TM_FORCE_DP") == "1"      # one-rank rehearsal of the RCCL path
-    reducer = unet_amd.GradientReducer(force=force_dp).attach(model) if (world > 1 or force_dp) else None
+    reducer = unet_amd.GradientReducer(bucket_bytes=int(args.bucket_mb * (1 << 20)), force=force_dp).attach(model) if (world > 1 or force_dp) else None
     if world > 1 or force_dp:
         model.flat_parameters()
         unet_amd.broadcast_parameters(model)
@@ -151,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3    # host time to enqueue a step
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -207,7 +209,7 @@ def main():
         out = {
             "metric": "U-Net train TMs/sec (fwd+bwd)" if train else "U-Net inference TMs/sec",
             "value": round(value, 1), "unit": "TMs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(host_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": args.workload, "in_channels": cin, "out_channels": cout, "features": list(feats),
                        "height": H, "width": W, "per_gpu_batch": batch, "global_batch": batch * world,

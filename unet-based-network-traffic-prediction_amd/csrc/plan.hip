@@ -79,6 +79,11 @@ struct mi_unet_plan {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
   size_t events_used;
+  // captured launch sequences (see run_graphed)
+  struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; int state; };  // state 0 seen once, 1 ready, -1 unusable
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream;
+  int graph_mode;              // -1 not read yet, 0 off, 1 on
   // second stream for the weight-gradient kernels of a backward call (see fork_side)
   hipStream_t side;
   bool side_tried, side_busy;
@@ -245,6 +250,62 @@ int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float a
   return MI_OK;
 }
 
+// Launch-sequence graphs.  A training step is ~110 dependent launches of 10-30 us kernels: issued
+// one by one the host barely keeps ahead of the GPU.  The part of a forward / backward call that
+// touches only plan-owned memory (workspace, packed weights) and the caller's long-lived buffers
+// (flat parameters, flat gradients) is therefore captured into a HIP graph the second time the
+// same arguments are seen and replayed with one launch afterwards.  The kernels that read or
+// write per-call buffers (network input, prediction, loss gradient, input gradient) stay outside
+// the graph, so new batches never invalidate it.  Capture runs on a private stream (the caller's
+// may be the legacy default stream, which cannot capture); the side stream of the wgrad kernels
+// joins the capture through its fork/join events.
+// Off by default, UNET_TM_GRAPH=1 turns it on: measured on MI355X (batch 512, 32x32) the step is
+// GPU-bound, replay is no faster than eager launches on one stream (1.81 ms either way), and a
+// graph loses the overlap the eager two-stream backward gets (1.83 ms against 1.70 ms).  It pays
+// only where the host cannot keep ahead (small batches, slow hosts).
+constexpr size_t kMaxGraphs = 12;
+template <typename Body>
+int run_graphed(mi_unet_plan* P, const std::vector<uint64_t>& key, hipStream_t stream, Body body) {
+  if (P->graph_mode < 0) {
+    const char* env = getenv("UNET_TM_GRAPH");
+    P->graph_mode = (env && env[0] == '1') ? 1 : 0;
+  }
+  if (P->profile || P->graph_mode == 0) return body(stream);
+  mi_unet_plan::GraphEntry* e = nullptr;
+  for (auto& g : P->graphs)
+    if (g.key == key) { e = &g; break; }
+  if (!e) {                                    // first sighting: run eagerly (also performs every lazy initialisation)
+    if (P->graphs.size() < kMaxGraphs) P->graphs.push_back({key, nullptr, 0});
+    return body(stream);
+  }
+  if (e->state < 0) return body(stream);
+  if (e->state == 0) {
+    e->state = -1;                             // stays unusable unless everything below succeeds
+    if (!P->cap_stream && hipStreamCreateWithFlags(&P->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+      P->cap_stream = nullptr;
+      return body(stream);
+    }
+    if (hipStreamBeginCapture(P->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return body(stream);
+    const int rc = body(P->cap_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(P->cap_stream, &graph);
+    if (rc != MI_OK || ec != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      return rc != MI_OK ? rc : body(stream);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) { (void)hipGetLastError(); return body(stream); }
+    e->exec = exec;
+    e->state = 1;
+  }
+  return check_hip(hipGraphLaunch(e->exec, stream), "graph launch");
+}
+enum Phase { PH_IN = 1, PH_BODY = 2, PH_OUT = 4, PH_ALL = 7 };
+uint64_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
 void bil_strides_nhwc(const Tensor& t, int64_t s[4]) {
   s[0] = (int64_t)t.H * t.W * t.cs; s[1] = 1; s[2] = (int64_t)t.W * t.cs; s[3] = t.cs;
 }
@@ -281,6 +342,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   P->profile = false;
   P->events_used = 0;
   P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0;
+  P->cap_stream = nullptr; P->graph_mode = -1;
   P->h.resize(L + 1); P->w.resize(L + 1);
   P->h[0] = d.height; P->w[0] = d.width;
   for (int l = 0; l < L; ++l) { P->h[l + 1] = P->h[l] / 2; P->w[l + 1] = P->w[l] / 2; }
@@ -445,6 +507,9 @@ void mi_unet_plan_destroy(mi_unet_plan* plan) {
   for (hipEvent_t e : plan->event_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : plan->sync_pool) (void)hipEventDestroy(e);
   if (plan->side) (void)hipStreamDestroy(plan->side);
+  for (auto& g : plan->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (plan->cap_stream) (void)hipStreamDestroy(plan->cap_stream);
   delete plan;
 }
 size_t mi_unet_plan_workspace_bytes(const mi_unet_plan* plan) { return plan ? plan->ws_bytes : 0; }
@@ -513,16 +578,24 @@ int mi_unet_profile_read(mi_unet_plan* plan, int i, char* kernel, int kcap, char
   return MI_OK;
 }
 
-int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_flat, void* ws, size_t ws_bytes,
-                    float* pred_nchw, int flags, mi_stream stream) {
-  MI_REQUIRE(P && x_nchw && params_flat && ws && pred_nchw, "unet_forward: null pointer");
-  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_forward: workspace too small");
-  MI_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)params_flat & 15) == 0, "unet_forward: workspace must be 256-byte aligned");
+}  // extern "C"
+
+namespace {
+// phases: PH_IN = input layout (reads x_nchw), PH_BODY = everything on plan-owned memory,
+// PH_OUT = head and forced output resize (write pred_nchw)
+int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_flat, void* ws, float* pred_nchw,
+                   int flags, hipStream_t stream, int phases) {
   const mi_unet_desc& d = P->d;
   const int L = P->L, B = d.batch, dt = d.dtype;
-  Run r{P, (char*)ws, params_flat, (hipStream_t)stream, 0};
-  if (P->profile) { P->prof.clear(); P->events_used = 0; }
+  Run r{P, (char*)ws, params_flat, stream, 0};
 
+  if (phases & PH_IN) {
+    Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
+    sc.kernel("nchw_to_nhwc");
+    View x = r.view("x");
+    RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
+  }
+  if (phases & PH_BODY) {
   if (flags & MI_FWD_REPACK) {
     const bool train = (flags & MI_FWD_TRAIN) != 0;
     Scope sc(P, r.s, "pack_weights", 0, 0);
@@ -537,12 +610,6 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
         return fail(MI_EINVAL, "unet_forward: layer too large to pack");
     }
     RUN(launch_pack_multi(J, dt, r.s));
-  }
-  {
-    Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
-    sc.kernel("nchw_to_nhwc");
-    View x = r.view("x");
-    RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
   }
   View cur = r.view("x");
   for (int l = 0; l < L; ++l) {
@@ -603,8 +670,10 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
     RUN(do_conv_fwd(r, c2, u1, u2, B, P->h[l], P->w[l], c2.prefix.c_str()));
     cur = u2;
   }
-  {
+  }  // PH_BODY
+  if (phases & PH_OUT) {
     const Layer& hd = P->layers.back();
+    View cur = r.view("u2." + std::to_string(L - 1));
     float* pred0 = P->out_resize ? (float*)(r.ws + P->tensors[P->tensor_id("pred0")].off) : pred_nchw;
     {
       Scope sc(P, r.s, "final_conv", 2.0 * B * d.height * d.width * (double)hd.cin * hd.cout,
@@ -621,23 +690,43 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
                               d.out_h, d.out_w, r.s));
     }
   }
+  return MI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_flat, void* ws, size_t ws_bytes,
+                    float* pred_nchw, int flags, mi_stream stream) {
+  MI_REQUIRE(P && x_nchw && params_flat && ws && pred_nchw, "unet_forward: null pointer");
+  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_forward: workspace too small");
+  MI_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)params_flat & 15) == 0, "unet_forward: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (P->profile) { P->prof.clear(); P->events_used = 0; }
+  RUN(forward_phases(P, x_nchw, params_flat, ws, pred_nchw, flags, s, PH_IN));
+  const std::vector<uint64_t> key = {1u, (uint64_t)(uintptr_t)params_flat, (uint64_t)(uintptr_t)ws, (uint64_t)flags};
+  RUN(run_graphed(P, key, s, [&](hipStream_t cs) {
+    return forward_phases(P, x_nchw, params_flat, ws, pred_nchw, flags, cs, PH_BODY);
+  }));
+  RUN(forward_phases(P, x_nchw, params_flat, ws, pred_nchw, flags, s, PH_OUT));
   P->forward_done = true;
   return MI_OK;
 }
 
-int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* params_flat, void* ws, size_t ws_bytes,
-                     float* grads, float alpha, float beta, int seg_lo, int seg_hi, float* dx_nchw, mi_stream stream) {
-  MI_REQUIRE(P && dpred_nchw && params_flat && ws && grads, "unet_backward: null pointer");
-  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_backward: workspace too small");
-  if (!P->forward_done) return fail(MI_ESTATE, "unet_backward: no forward pass has been run on this plan");
-  const int nseg = (int)P->segs.size();
-  MI_REQUIRE(seg_lo >= 0 && seg_hi <= nseg && seg_lo <= seg_hi, "unet_backward: bad segment range");
-  MI_REQUIRE(!P->d.need_input_grad || dx_nchw || seg_hi < nseg, "unet_backward: dx buffer required");
+}  // extern "C"
+
+namespace {
+// phases: PH_IN = segment 0, the head (reads dpred_nchw), PH_BODY = the other segments,
+// PH_OUT = layout change of the input gradient (writes dx_nchw)
+int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* params_flat, void* ws, float* grads,
+                    float alpha, float beta, int seg_lo, int seg_hi, float* dx_nchw, hipStream_t stream, int phases) {
   const mi_unet_desc& d = P->d;
   const int L = P->L, B = d.batch, dt = d.dtype;
-  Run r{P, (char*)ws, params_flat, (hipStream_t)stream, 0};
+  Run r{P, (char*)ws, params_flat, stream, 0};
 
   for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    const int seg_phases = seg == 0 ? PH_IN : (seg >= L + 2 ? PH_BODY | PH_OUT : PH_BODY);
+    if (!(phases & seg_phases)) continue;
     if (seg == 0) {
       // ---- head (and the forced output resize in front of it)
       const Layer& hd = P->layers.back();
@@ -733,30 +822,61 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
       const int H = P->h[l], W = P->w[l];
       View a1 = r.view("a1." + s), ga1 = r.view("g.a1." + s);
       View cat = r.view("cat." + s), gcat = r.view("g.cat." + s), gpool = r.view("g.pool." + s);
-      {
-        Scope sc(P, r.s, ("pool." + s + ".bwd").c_str(), 0, (double)B * H * W * f * 3.25 * esz(P));
-        sc.kernel("maxpool2_bwd");
-        RUN(launch_maxpool2_bwd(cat.p, cat.cs, 0, gpool.p, gpool.cs, 0, gcat.p, gcat.cs, 0, gcat.p, gcat.cs, 0, B, H, W,
-                                f, 1, dt, r.s));
+      if (phases & PH_BODY) {
+        {
+          Scope sc(P, r.s, ("pool." + s + ".bwd").c_str(), 0, (double)B * H * W * f * 3.25 * esz(P));
+          sc.kernel("maxpool2_bwd");
+          RUN(launch_maxpool2_bwd(cat.p, cat.cs, 0, gpool.p, gpool.cs, 0, gcat.p, gcat.cs, 0, gcat.p, gcat.cs, 0, B, H, W,
+                                  f, 1, dt, r.s));
+        }
+        View gy{gcat.p, gcat.cs, 0};
+        RUN(do_conv_wgrad(r, c2, a1, gy, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
+        RUN(do_conv_dgrad(r, c2, gy, ga1, &a1, B, H, W, (c2.prefix + ".dgrad").c_str()));
+        View xin = l == 0 ? r.view("x") : r.view("pool." + std::to_string(l - 1));
+        RUN(do_conv_wgrad(r, c1, xin, ga1, grads, alpha, beta, B, H, W, (c1.prefix + ".wgrad").c_str()));
+        if (l > 0) {
+          View gxin = r.view("g.pool." + std::to_string(l - 1));
+          RUN(do_conv_dgrad(r, c1, ga1, gxin, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
+        } else if (d.need_input_grad) {
+          View gx = r.view("g.x");
+          RUN(do_conv_dgrad(r, c1, ga1, gx, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
+        }
       }
-      View gy{gcat.p, gcat.cs, 0};
-      RUN(do_conv_wgrad(r, c2, a1, gy, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
-      RUN(do_conv_dgrad(r, c2, gy, ga1, &a1, B, H, W, (c2.prefix + ".dgrad").c_str()));
-      View xin = l == 0 ? r.view("x") : r.view("pool." + std::to_string(l - 1));
-      RUN(do_conv_wgrad(r, c1, xin, ga1, grads, alpha, beta, B, H, W, (c1.prefix + ".wgrad").c_str()));
-      if (l > 0) {
-        View gxin = r.view("g.pool." + std::to_string(l - 1));
-        RUN(do_conv_dgrad(r, c1, ga1, gxin, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
-      } else if (d.need_input_grad) {
+      if ((phases & PH_OUT) && l == 0 && d.need_input_grad) {
         View gx = r.view("g.x");
-        RUN(do_conv_dgrad(r, c1, ga1, gx, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
         Scope sc(P, r.s, "input_grad_nchw", 0, (double)B * H * W * d.in_channels * (4 + esz(P)));
         sc.kernel("nhwc_to_nchw");
         RUN(launch_nhwc_to_nchw(gx.p, gx.cs, 0, dx_nchw, B, d.in_channels, H, W, dt, r.s));
       }
     }
   }
-  return join_side(r);
+  return (phases & PH_BODY) ? join_side(r) : MI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* params_flat, void* ws, size_t ws_bytes,
+                     float* grads, float alpha, float beta, int seg_lo, int seg_hi, float* dx_nchw, mi_stream stream) {
+  MI_REQUIRE(P && dpred_nchw && params_flat && ws && grads, "unet_backward: null pointer");
+  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_backward: workspace too small");
+  if (!P->forward_done) return fail(MI_ESTATE, "unet_backward: no forward pass has been run on this plan");
+  const int nseg = (int)P->segs.size();
+  MI_REQUIRE(seg_lo >= 0 && seg_hi <= nseg && seg_lo <= seg_hi, "unet_backward: bad segment range");
+  MI_REQUIRE(!P->d.need_input_grad || dx_nchw || seg_hi < nseg, "unet_backward: dx buffer required");
+  hipStream_t s = (hipStream_t)stream;
+  if (seg_lo == 0 && seg_hi > 0)
+    RUN(backward_phases(P, dpred_nchw, params_flat, ws, grads, alpha, beta, 0, 1, dx_nchw, s, PH_IN));
+  const int lo = seg_lo > 1 ? seg_lo : 1;
+  if (lo < seg_hi) {
+    const std::vector<uint64_t> key = {2u, (uint64_t)(uintptr_t)params_flat, (uint64_t)(uintptr_t)ws,
+                                       (uint64_t)(uintptr_t)grads, fbits(alpha), fbits(beta), (uint64_t)lo, (uint64_t)seg_hi};
+    RUN(run_graphed(P, key, s, [&](hipStream_t cs) {
+      return backward_phases(P, dpred_nchw, params_flat, ws, grads, alpha, beta, lo, seg_hi, dx_nchw, cs, PH_BODY);
+    }));
+    RUN(backward_phases(P, dpred_nchw, params_flat, ws, grads, alpha, beta, lo, seg_hi, dx_nchw, s, PH_OUT));
+  }
+  return MI_OK;
 }
 
 }  // extern "C"

@@ -140,6 +140,7 @@ class UNet(nn.Module):
         self._flat_layout: List[Tuple[int, int, torch.Size]] = []
         self._last_pred: Optional[torch.Tensor] = None
         self._dp = None               # set by distributed.GradientReducer.attach
+        self._grad_stage: Optional[torch.Tensor] = None
         self.last_plan: Optional[_Plan] = None
 
     # ------------------------------------------------------------------ parameters
@@ -162,6 +163,7 @@ class UNet(nn.Module):
     def _apply(self, fn, *a, **kw):
         # .to()/.cuda()/.float() replace parameter storage: the flat buffer must be rebuilt
         self._flat = None
+        self._grad_stage = None
         self._plans.clear()
         return super()._apply(fn, *a, **kw)
 
@@ -256,8 +258,14 @@ class UNet(nn.Module):
         dpred = dpred.contiguous()
         if dpred.dtype != torch.float32:
             dpred = dpred.float()
-        if out is None:
-            out = torch.zeros_like(flat)
+        # Gradients are produced in a buffer that lives as long as the module: its address is part
+        # of the key of the library's captured launch graphs, so it must not change from step to
+        # step.  Callers get a copy (autograd may keep or accumulate into what it is handed).
+        staged = out is None
+        if staged:
+            if self._grad_stage is None or self._grad_stage.shape != flat.shape or self._grad_stage.device != flat.device:
+                self._grad_stage = torch.zeros_like(flat)
+            out = self._grad_stage
         dx = None
         if plan.need_input_grad:
             dx = torch.empty((plan.B, self.in_channels, plan.H, plan.W), device=flat.device, dtype=torch.float32)
@@ -276,6 +284,8 @@ class UNet(nn.Module):
                                          dx.data_ptr() if dx is not None else None, stream), "unet_backward")
                 dp.reduce_async(out[lo:hi])
             dp.wait_all()
+        if staged:
+            out = out.clone()
         return out, dx
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
