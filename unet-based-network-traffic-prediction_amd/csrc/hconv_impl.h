@@ -36,13 +36,22 @@ struct HconvArgs {
   int bands;                            // tiles per image (1 when a tile holds whole images)
   int ntiles, nchunks;
   const void* zero;                     // zero page
+  FastDiv d_grp, d_pitch, d_rw, d_w, d_bands;   // by (R+2)*pitch, pitch, R*W, W, bands (filled in by the launcher)
 };
 
 constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 64)
 constexpr int kHconvBigHalo = 768;      // 4x4 images (16 per tile, pitch 8): needs the narrower channel tiles
 
+// Bank swizzle of the pixel tile: the 16-byte chunk index of halo slot hr is XORed with 2*bit.
+// 16 consecutive slots (W >= 8) need bit 2 of hr; on 4x4 images (pitch 8) a 16-pixel MFMA tile is
+// slots {0-3, 8-11, 16-19, 24-27}, whose bit 2 is constant -- a 4-way conflict -- and bit 3 (the
+// halo row parity) is the one that spreads them.  A vertical tap shift of one row flips bit 3, so
+// that variant flips the chunk bit of the precomputed fragment address for odd ty.
+template <bool ROWPAR> __device__ __forceinline__ int hswz(int hr) { return ROWPAR ? (hr >> 2) & 2 : (hr >> 1) & 2; }
+
 template <typename T, int TN, int MH, int TM>
 __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const HconvArgs a) {
+  constexpr bool ROWPAR = MH > kHconvMaxHalo;    // the wide-halo variant serves 4x4 images only
   typedef typename ElemTraits<T>::frag_t frag_t;
   constexpr int EPC = ElemTraits<T>::EPC;
   constexpr int CK = 4 * EPC;                    // channels per 64-byte chunk
@@ -74,12 +83,12 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
     const int hr = id >> 2, ch = id & 3;
     relcs[i] = 0; lds_a[i] = -1;
     if (hr < a.HR) {
-      const int g = hr / grp_rows, rem = hr - g * grp_rows;
-      const int hy = rem / a.pitch, hx = rem - hy * a.pitch;
+      const int g = (int)fdiv((uint32_t)hr, a.d_grp), rem = hr - g * grp_rows;
+      const int hy = (int)fdiv((uint32_t)rem, a.d_pitch), hx = rem - hy * a.pitch;
       if (hx <= a.W + 1) {
         relcs[i] = (g * a.R * a.W + (hy - 1) * a.W + (hx - 1)) * a.in_cs;
         const int kind = (hx == 0 || hx == a.W + 1) ? 1 : (hy == 0 ? 2 : (hy == a.R + 1 ? 3 : 0));
-        lds_a[i] = (hr * 64 + ((ch ^ ((hr >> 1) & 2)) << 4)) | kind;
+        lds_a[i] = (hr * 64 + ((ch ^ hswz<ROWPAR>(hr)) << 4)) | kind;
       }
     }
   }
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 #pragma unroll
   for (int i = 0; i < W_IT; ++i) {
     const int id = t + NT * i, row = id >> 2;
-    const int tap = row / BN, n = row - tap * BN;
+    const int tap = row / BN, n = row - tap * BN;   // BN is a power of two
     woff[i] = row < 9 * BN ? (n0 + n) * a.Kp + tap * a.Cp + chq : -1;
   }
 
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 #pragma unroll
   for (int i = 0; i < W_IT; ++i) { rw0[i] = u32x4_t{0u, 0u, 0u, 0u}; rw1[i] = u32x4_t{0u, 0u, 0u, 0u}; }
   auto load_a = [&](a_regs_t& ra, int tile, int chunk) {
-    const int band = tile % a.bands;
+    const int band = tile - (int)fdiv((uint32_t)tile, a.d_bands) * a.bands;
     const bool top0 = band == 0, bot0 = band == a.bands - 1;
     const int64_t base = (int64_t)tile * BM * a.in_cs + a.in_co + chunk * CK + chq;
 #pragma unroll
@@ -141,13 +150,13 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int pl = (wave * TM + j) * 16 + r16;         // pixel index inside the tile
-    const int g = pl / (a.R * a.W), rem = pl - g * (a.R * a.W);
-    const int y = rem / a.W, x = rem - y * a.W;
+    const int g = (int)fdiv((uint32_t)pl, a.d_rw), rem = pl - g * (a.R * a.W);
+    const int y = (int)fdiv((uint32_t)rem, a.d_w), x = rem - y * a.W;
     const int hrow = g * grp_rows + y * a.pitch + x;   // halo slot of tap (0,0)
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
       const int hr = hrow + tx;
-      paddr[j][tx] = hr * 64 + ((ch ^ ((hr >> 1) & 2)) << 4);
+      paddr[j][tx] = hr * 64 + ((ch ^ hswz<ROWPAR>(hr)) << 4);
     }
     out_off[j] = pl * a.out_cs + a.out_co + n0 + 4 * ch;
     mask_off[j] = pl * a.mask_cs + a.mask_co + n0 + 4 * ch;
@@ -169,8 +178,9 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
     auto read_tap = [&](int tap, int set) {
       const int ty = tap / 3, tx = tap % 3;
       const char* Sy = S + ty * ty_bytes;
+      const int flip = (ROWPAR && (ty & 1)) ? 32 : 0;
 #pragma unroll
-      for (int j = 0; j < TM; ++j) pf[set][j] = *(const frag_t*)(Sy + paddr[j][tx]);
+      for (int j = 0; j < TM; ++j) pf[set][j] = *(const frag_t*)(Sy + (paddr[j][tx] ^ flip));
 #pragma unroll
       for (int i = 0; i < TN; ++i) wf[set][i] = *(const frag_t*)(S + (tap * BN + i * 16) * 64 + wfrag_off);
     };
@@ -306,7 +316,10 @@ inline bool hconv_tiling(int H, int W, int* R, int* G, int* bands) {
 }
 
 template <typename T>
-static int launch_hconv_t(const HconvArgs& a, hipStream_t s, const char** name) {
+static int launch_hconv_t(const HconvArgs& a_in, hipStream_t s, const char** name) {
+  HconvArgs a = a_in;
+  a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
+  a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
   const bool bighalo = a.HR > kHconvMaxHalo;    // the larger halo buffer leaves LDS room for 32 channels
   const int bn = (a.N % 64 == 0 && !bighalo) ? 64 : (a.N % 32 == 0) ? 32 : 16;
   const int ny = a.N / bn;

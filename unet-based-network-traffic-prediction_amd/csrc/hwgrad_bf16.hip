@@ -68,8 +68,8 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
     const int id = t + 512 * i, hr = id >> 2, ch = id & 3;
     xrel[i] = 0; xlds[i] = -1;
     if (hr < a.HR) {
-      const int g = hr / grp_rows, rem = hr - g * grp_rows;
-      const int hy = rem / a.pitch, hx = rem - hy * a.pitch;
+      const int g = (int)fdiv((uint32_t)hr, a.d_grp), rem = hr - g * grp_rows;
+      const int hy = (int)fdiv((uint32_t)rem, a.d_pitch), hx = rem - hy * a.pitch;
       if (hx <= a.W + 1) {
         xrel[i] = g * a.R * a.W + (hy - 1) * a.W + (hx - 1);
         const int kind = (hx == 0 || hx == a.W + 1) ? 1 : (hy == 0 ? 2 : (hy == a.R + 1 ? 3 : 0));
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
   u32x4_t rdy[DY_IT], rx[X_IT];
   auto load_tile = [&](int tile) {
     const int64_t base = (int64_t)tile * 256;
-    const int band = tile % a.bands;
+    const int band = tile - (int)fdiv((uint32_t)tile, a.d_bands) * a.bands;
     const bool top0 = band == 0, bot0 = band == a.bands - 1;
 #pragma unroll
     for (int i = 0; i < DY_IT; ++i) {
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
         const int col = np * 32 + nt * 16 + 4 * pp;                // channel inside the dy tile
         a_addr[k][nt][h] = dy_off<NB>(pl, col >> 3) + (col & 7) * 2;
       }
-      const int gi = pl / (a.R * a.W), rem = pl - gi * (a.R * a.W);
-      const int y = rem / a.W, xx = rem - y * a.W;
+      const int gi = (int)fdiv((uint32_t)pl, a.d_rw), rem = pl - gi * (a.R * a.W);
+      const int y = (int)fdiv((uint32_t)rem, a.d_w), xx = rem - y * a.W;
       const int hrow = gi * grp_rows + y * a.pitch + xx;            // halo row of tap (0,0)
 #pragma unroll
       for (int tx = 0; tx < 3; ++tx) {
@@ -275,7 +275,10 @@ bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR
 }
 int hwgrad_slabs_per_split(int) { return 1; }
 
-int launch_hwgrad_bf16(const HwgradArgs& a, hipStream_t s, const char** name) {
+int launch_hwgrad_bf16(const HwgradArgs& a_in, hipStream_t s, const char** name) {
+  HwgradArgs a = a_in;
+  a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
+  a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
   if (a.Na % 64 == 0) {
     dim3 grid(a.Na / 64, a.Cb / 32, a.splits);
     if (name) *name = "hwgrad_64x32x9";

@@ -437,6 +437,9 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     const int f = d.features[l];
     add_tensor(P, "g.a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
     add_tensor(P, "g.cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
+    // total gradient of the skip tensor (concat half + pool path, ReLU-masked), stored densely: the
+    // encoder's wgrad/dgrad then read whole rows instead of half of every g.cat row
+    add_tensor(P, "g.skip." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
     add_tensor(P, "g.pool." + std::to_string(l), B, P->h[l + 1], P->w[l + 1], f, 0, cur);
   }
   add_tensor(P, "g.b1", B, P->h[L], P->w[L], 2 * fb, 0, cur);
@@ -480,7 +483,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     for (int l = 0; l < L; ++l) {
       const int f = d.features[l]; const std::string s = std::to_string(l);
       name_view(a + "downs." + s + ".1", t + "a1." + s, 0, f);
-      name_view(a + "downs." + s + ".3", t + "cat." + s, 0, f);
+      name_view(a + "downs." + s + ".3", pass ? "g.skip." + s : "cat." + s, 0, f);
       name_view(a + "pool." + s, t + "pool." + s, 0, f);
     }
     name_view(a + "bottleneck.1", t + "b1", 0, 2 * fb);
@@ -822,14 +825,15 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
       const int H = P->h[l], W = P->w[l];
       View a1 = r.view("a1." + s), ga1 = r.view("g.a1." + s);
       View cat = r.view("cat." + s), gcat = r.view("g.cat." + s), gpool = r.view("g.pool." + s);
+      View gskip = r.view("g.skip." + s);
       if (phases & PH_BODY) {
         {
           Scope sc(P, r.s, ("pool." + s + ".bwd").c_str(), 0, (double)B * H * W * f * 3.25 * esz(P));
           sc.kernel("maxpool2_bwd");
-          RUN(launch_maxpool2_bwd(cat.p, cat.cs, 0, gpool.p, gpool.cs, 0, gcat.p, gcat.cs, 0, gcat.p, gcat.cs, 0, B, H, W,
+          RUN(launch_maxpool2_bwd(cat.p, cat.cs, 0, gpool.p, gpool.cs, 0, gcat.p, gcat.cs, 0, gskip.p, gskip.cs, 0, B, H, W,
                                   f, 1, dt, r.s));
         }
-        View gy{gcat.p, gcat.cs, 0};
+        View gy = gskip;
         RUN(do_conv_wgrad(r, c2, a1, gy, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
         RUN(do_conv_dgrad(r, c2, gy, ga1, &a1, B, H, W, (c2.prefix + ".dgrad").c_str()));
         View xin = l == 0 ? r.view("x") : r.view("pool." + std::to_string(l - 1));
