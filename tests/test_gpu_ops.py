@@ -45,7 +45,9 @@ def gen(*shape, seed=0, scale=1.0, shift=0.0):
                                    (70, 128, 64, 4, 4, 0), (3, 128, 128, 2, 4, 64), (600, 64, 128, 4, 4, 0),
                                    (130, 64, 64, 1, 3, 0),
                                    # 4x4 images, 16 per halo tile (the wide-halo variant of the tile kernel)
-                                   (32, 64, 96, 4, 4, 0), (48, 32, 16, 4, 4, 0), (16, 128, 64, 4, 4, 64)])
+                                   (32, 64, 96, 4, 4, 0), (48, 32, 16, 4, 4, 0), (16, 128, 64, 4, 4, 64),
+                                   # wide images: two 128-pixel rows per halo tile
+                                   (2, 32, 64, 4, 128, 0), (1, 64, 32, 6, 128, 32)])
 def test_conv3x3_fwd_dgrad_wgrad(ua, dtype, shape):
     B, Cin, Cout, H, W, split = shape
     ops = ua.ops

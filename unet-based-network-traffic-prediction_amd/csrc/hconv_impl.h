@@ -39,7 +39,7 @@ struct HconvArgs {
   FastDiv d_grp, d_pitch, d_rw, d_w, d_bands;   // by (R+2)*pitch, pitch, R*W, W, bands (filled in by the launcher)
 };
 
-constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 64)
+constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 128)
 constexpr int kHconvBigHalo = 768;      // 4x4 images (16 per tile, pitch 8): needs the narrower channel tiles
 
 // Bank swizzle of the pixel tile: the 16-byte chunk index of halo slot hr is XORed with 2*bit.
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 
 // Tiling of an (H, W) image into 256-pixel tiles; returns false when the halo kernel does not apply.
 inline bool hconv_tiling(int H, int W, int* R, int* G, int* bands) {
-  if (W < 4 || W > 64) return false;
+  if (W < 4 || W > 128) return false;
   const int HW = H * W;
   if (HW >= 256) {
     if (256 % W != 0) return false;
