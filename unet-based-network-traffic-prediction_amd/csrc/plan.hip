@@ -20,6 +20,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -129,6 +130,8 @@ struct Run {   // per-call context
   const float* params;
   hipStream_t s;
   int rc;
+  // weight-gradient launches of the current backward segment, issued together by flush_wgrads()
+  std::vector<std::function<int(hipStream_t)>> deferred;
   View view(const std::string& name, int coff = 0) const {
     const int id = P->tensor_id(name);
     const Tensor& t = P->tensors[id];
@@ -234,20 +237,40 @@ int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, in
 }
 int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float alpha, float beta, int B, int H, int W,
                   const char* label) {
-  const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
-  const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
-  hipStream_t ws = fork_side(r);
-  for (int phase = 1; phase <= 2; ++phase) {
-    Scope sc(r.P, ws, phase == 1 ? label : (std::string(label) + ".reduce").c_str(), phase == 1 ? fl : 0.0,
-             phase == 1 ? by : 4.0 * l.cout * l.cin * 9);
-    const char* k = phase == 1 ? nullptr : "finalize_conv3";
-    int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
-                               r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout,
-                               r.P->d.dtype, ws, phase == 1 ? &k : nullptr, phase);
-    sc.kernel(k);
-    if (rc) return rc;
-  }
+  const std::string lab = label;
+  const Layer* lp = &l;
+  Run* rp = &r;
+  r.deferred.push_back([=](hipStream_t ws) -> int {
+    const Layer& l = *lp;
+    Run& r = *rp;
+    const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
+    const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
+    for (int phase = 1; phase <= 2; ++phase) {
+      Scope sc(r.P, ws, phase == 1 ? lab.c_str() : (lab + ".reduce").c_str(), phase == 1 ? fl : 0.0,
+               phase == 1 ? by : 4.0 * l.cout * l.cin * 9);
+      const char* k = phase == 1 ? nullptr : "finalize_conv3";
+      int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
+                                 r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout,
+                                 r.P->d.dtype, ws, phase == 1 ? &k : nullptr, phase);
+      sc.kernel(k);
+      if (rc) return rc;
+    }
+    return MI_OK;
+  });
   return MI_OK;
+}
+// Issues the deferred weight-gradient launches of a segment on the side stream behind ONE fork:
+// an event record + stream wait per layer costs more host time than the launches themselves.
+int flush_wgrads(Run& r) {
+  if (r.deferred.empty()) return MI_OK;
+  hipStream_t ws = fork_side(r);
+  int rc = MI_OK;
+  for (auto& f : r.deferred) {
+    rc = f(ws);
+    if (rc) break;
+  }
+  r.deferred.clear();
+  return rc;
 }
 
 // Launch-sequence graphs.  A training step is ~110 dependent launches of 10-30 us kernels: issued
@@ -782,18 +805,24 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
       View prev = j == 0 ? r.view("b2") : r.view("u2." + std::to_string(j - 1));
       View gprev = j == 0 ? r.view("g.b2") : r.view("g.u2." + std::to_string(j - 1));
       {
-        const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
-        hipStream_t ws = fork_side(r);
-        for (int phase = 1; phase <= 2; ++phase) {
-          Scope sc(P, ws, (up.prefix + (phase == 1 ? ".wgrad" : ".wgrad.reduce")).c_str(), phase == 1 ? fl : 0.0,
-                   phase == 1 ? (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P) : 16.0 * up.cin * up.cout);
-          const char* k = phase == 1 ? nullptr : "finalize_convt";
-          int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
-                                   alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
-                                   ws, phase == 1 ? &k : nullptr, phase);
-          sc.kernel(k);
-          RUN(rc);
-        }
+        const Layer* upp = &up;
+        Run* rp = &r;
+        r.deferred.push_back([=](hipStream_t ws) -> int {
+          const Layer& up = *upp;
+          Run& r = *rp;
+          const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
+          for (int phase = 1; phase <= 2; ++phase) {
+            Scope sc(P, ws, (up.prefix + (phase == 1 ? ".wgrad" : ".wgrad.reduce")).c_str(), phase == 1 ? fl : 0.0,
+                     phase == 1 ? (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P) : 16.0 * up.cin * up.cout);
+            const char* k = phase == 1 ? nullptr : "finalize_convt";
+            int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
+                                     alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
+                                     ws, phase == 1 ? &k : nullptr, phase);
+            sc.kernel(k);
+            if (rc) return rc;
+          }
+          return MI_OK;
+        });
       }
       {
         const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
@@ -853,6 +882,7 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
         RUN(launch_nhwc_to_nchw(gx.p, gx.cs, 0, dx_nchw, B, d.in_channels, H, W, dt, r.s));
       }
     }
+    RUN(flush_wgrads(r));
   }
   return (phases & PH_BODY) ? join_side(r) : MI_OK;
 }

@@ -147,7 +147,11 @@ class UNet(nn.Module):
     def _construction_order(self) -> List[nn.Parameter]:
         """Parameters in the order the layers are constructed = forward execution order
         (downs, bottleneck, ups, final_conv); the flat buffer uses this order so that
-        gradients become ready back-to-front during backward."""
+        gradients become ready back-to-front during backward.  Cached: walking the module
+        containers costs more host time per step than everything else in forward()."""
+        cached = self.__dict__.get("_param_list")
+        if cached is not None:
+            return cached
         mods = []
         for blk in self.downs:
             mods += [blk[0], blk[2]]
@@ -158,6 +162,7 @@ class UNet(nn.Module):
         out = []
         for m in mods:
             out += [m.weight, m.bias]
+        self.__dict__["_param_list"] = out
         return out
 
     def _apply(self, fn, *a, **kw):
@@ -165,7 +170,11 @@ class UNet(nn.Module):
         self._flat = None
         self._grad_stage = None
         self._plans.clear()
-        return super()._apply(fn, *a, **kw)
+        self.__dict__.pop("_param_list", None)
+        try:
+            return super()._apply(fn, *a, **kw)
+        finally:
+            self.__dict__.pop("_param_list", None)   # _apply may replace Parameter objects
 
     def _ensure_flat(self, device: torch.device) -> torch.Tensor:
         params = self._construction_order()
