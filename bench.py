@@ -55,7 +55,22 @@ def read_profile(model):
     return out
 
 
-def cpu_baseline(cin, cout, feats, H, W, batch, budget_s=20.0):
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the newest committed PMC summary (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over this same workload, see scripts/pmc_traffic.py), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return (k["traffic"], os.path.basename(files[-1])) if k else (None, None)
+    except Exception:
+        return None, None
+
+
+def cpu_baseline(cin, cout, feats, H, W, batch, budget_s=12.0):
     from oracle import unet_oracle as O
     cores = os.cpu_count() or 1
     try:
@@ -70,7 +85,7 @@ def cpu_baseline(cin, cout, feats, H, W, batch, budget_s=20.0):
     t0 = time.perf_counter()
     O.train_steps(state, [(X, Y)], lr=1e-4)            # warm-up step
     warm = time.perf_counter() - t0
-    n = max(2, min(20, int(budget_s / max(warm, 1e-3))))
+    n = max(2, min(400, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     O.train_steps(state, [(X, Y)] * n, lr=1e-4)
     dt = time.perf_counter() - t0
@@ -196,8 +211,10 @@ def main():
             if e["flops"] > 0:
                 ach = e["flops"] / e["launches"] / (avg_ms * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.dtype]
+                traffic, traffic_src = (pmc_traffic(dom) if args.workload == "cfg2_geant32_b512" and args.dtype == "bf16"
+                                        and batch == 512 else (None, None))
                 roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None,
+                        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "launches_per_step": e["launches"] // args.profile_steps, "avg_launch_ms": round(avg_ms, 5),
                         "share_of_gpu_time": round(e["ms"] / args.profile_steps / gpu_ms, 3)}
             else:
