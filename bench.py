@@ -5,7 +5,7 @@
 
 A step is the loop body of the reference's train_one_epoch (train.py:382-393) on one batch of
 synthetic traffic matrices already resident in HBM: forward, MSE loss, zero_grad, backward,
-Adam step.  The default workload is BASELINE.json's configs[1]: unet2d on GEANT-shaped 23x23
+Adam step.  The default workload is the headline configuration: unet2d on GEANT-shaped 23x23
 matrices padded to 32x32, 12 past steps as channels -> 1 step, batch 512 per GPU, bf16
 compute with fp32 accumulation/master weights.  With N > 1 (one process per GPU, launched by
 torch.distributed.run) every rank runs the same per-GPU batch on its own shard (weak
