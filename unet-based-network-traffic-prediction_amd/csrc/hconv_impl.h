@@ -21,6 +21,7 @@
 //     a stage is issued back to back and waited for only at the LDS store after the MFMA phase.
 #pragma once
 #include "igemm_impl.h"
+#include <cstdlib>
 
 namespace mi {
 
@@ -37,6 +38,7 @@ struct HconvArgs {
   int ntiles, nchunks;
   const void* zero;                     // zero page
   FastDiv d_grp, d_pitch, d_rw, d_w, d_bands;   // by (R+2)*pitch, pitch, R*W, W, bands (filled in by the launcher)
+  int dbg;
 };
 
 constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 128)
@@ -134,6 +136,15 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
     for (int i = 0; i < A_IT; ++i)
       if (lds_a[i] >= 0) *(u32x4_t*)(A + (lds_a[i] & ~15)) = ra[i];
   };
+  auto store_a_piece = [&](const a_regs_t& ra, int buf, int i) {
+    char* A = smem + buf * STAGE;
+    if (lds_a[i] >= 0) *(u32x4_t*)(A + (lds_a[i] & ~15)) = ra[i];
+  };
+  auto store_w_piece = [&](const w_regs_t& rw, int buf, int i) {
+    char* Wt = smem + buf * STAGE + A_BYTES;
+    const int id = t + NT * i, row = id >> 2, ch = id & 3;
+    if (row < 9 * BN) *(u32x4_t*)(Wt + row * 64 + ((ch ^ ((row >> 1) & 2)) << 4)) = rw[i];
+  };
   auto store_w = [&](const w_regs_t& rw, int buf) {
     char* Wt = smem + buf * STAGE + A_BYTES;
 #pragma unroll
@@ -171,8 +182,13 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
-  auto compute = [&](int buf) {
+  // MFMA phase of one staged chunk.  The LDS stores of the NEXT stage (registers loaded one stage
+  // ago, buffer last read one stage ago) are spread over the nine taps instead of following the
+  // MFMAs as a block: the LDS write path then works in the shadow of the matrix pipe and the
+  // workgroup does not sit through a store-only phase before every barrier.
+  auto compute = [&](int buf, const a_regs_t& held_a, const w_regs_t& held_w, bool st_a, bool st_w) {
     const char* S = smem + buf * STAGE;
+    const int nbuf = buf ^ 1;
     // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
     frag_t pf[2][TM], wf[2][TN];
     auto read_tap = [&](int tap, int set) {
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 #pragma unroll
       for (int i = 0; i < TN; ++i) wf[set][i] = *(const frag_t*)(S + (tap * BN + i * 16) * 64 + wfrag_off);
     };
+    constexpr int PIECES = A_IT + W_IT;
     read_tap(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -192,6 +209,12 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = mma_slab(wf[tap & 1][i], pf[tap & 1][j], acc[i][j]);
+      // pieces tap, tap+9, ... of the next stage's image
+#pragma unroll
+      for (int pc = tap; pc < PIECES; pc += 9) {
+        if (pc < A_IT) { if (st_a) store_a_piece(held_a, nbuf, pc); }
+        else if (st_w) store_w_piece(held_w, nbuf, pc - A_IT);
+      }
     }
   };
   T* __restrict__ out = (T*)a.out;
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   };
   // resident weights: stage parity selects the LDS buffer, so both buffers are filled by the
   // first two stages (with a single chunk that is the same chunk twice) and never again
-  auto stage_needs_w = [&](int s) { return !w_resident || s < 2; };
+  auto stage_needs_w = [&](int s) { return (!w_resident && !(a.dbg & 1)) || s < 2; };
 
   load_a(ra0, ltile, lchunk);
   load_w(rw0, lchunk);
@@ -276,18 +299,14 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   // `held` carries stage s+1 (already in flight), `fresh` receives stage s+2
   auto stage = [&](int s, a_regs_t& held_a, w_regs_t& held_w, a_regs_t& fresh_a, w_regs_t& fresh_w) {
     if (s + 2 < nstages) {
-      load_a(fresh_a, ltile, lchunk);
+      if (!(a.dbg & 4)) load_a(fresh_a, ltile, lchunk);
       if (stage_needs_w(s + 2)) load_w(fresh_w, lchunk);
       advance_load();
     }
-    compute(s & 1);
-    // LDS stores first: their vmcnt wait must not also cover the epilogue's global stores
-    if (s + 1 < nstages) {
-      store_a(held_a, (s + 1) & 1);
-      if (stage_needs_w(s + 1)) store_w(held_w, (s + 1) & 1);
-    }
+    const bool nxt = s + 1 < nstages;
+    compute(s & 1, held_a, held_w, nxt, nxt && stage_needs_w(s + 1));
     if (chunk == a.nchunks - 1) {
-      epilogue(tile);
+      if (!(a.dbg & 2)) epilogue(tile);
       zero_acc();
     }
     __syncthreads();
@@ -320,6 +339,7 @@ static int launch_hconv_t(const HconvArgs& a_in, hipStream_t s, const char** nam
   HconvArgs a = a_in;
   a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
   a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
+  a.dbg = getenv("HCONV_DBG") ? atoi(getenv("HCONV_DBG")) : 0;
   const bool bighalo = a.HR > kHconvMaxHalo;    // the larger halo buffer leaves LDS room for 32 channels
   const int bn = (a.N % 64 == 0 && !bighalo) ? 64 : (a.N % 32 == 0) ? 32 : 16;
   const int ny = a.N / bn;
