@@ -21,7 +21,6 @@
 //     a stage is issued back to back and waited for only at the LDS store after the MFMA phase.
 #pragma once
 #include "igemm_impl.h"
-#include <cstdlib>
 
 namespace mi {
 
@@ -38,7 +37,6 @@ struct HconvArgs {
   int ntiles, nchunks;
   const void* zero;                     // zero page
   FastDiv d_grp, d_pitch, d_rw, d_w, d_bands;   // by (R+2)*pitch, pitch, R*W, W, bands (filled in by the launcher)
-  int dbg;
 };
 
 constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 128)
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   };
   // resident weights: stage parity selects the LDS buffer, so both buffers are filled by the
   // first two stages (with a single chunk that is the same chunk twice) and never again
-  auto stage_needs_w = [&](int s) { return (!w_resident && !(a.dbg & 1)) || s < 2; };
+  auto stage_needs_w = [&](int s) { return !w_resident || s < 2; };
 
   load_a(ra0, ltile, lchunk);
   load_w(rw0, lchunk);
@@ -299,14 +297,14 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   // `held` carries stage s+1 (already in flight), `fresh` receives stage s+2
   auto stage = [&](int s, a_regs_t& held_a, w_regs_t& held_w, a_regs_t& fresh_a, w_regs_t& fresh_w) {
     if (s + 2 < nstages) {
-      if (!(a.dbg & 4)) load_a(fresh_a, ltile, lchunk);
+      load_a(fresh_a, ltile, lchunk);
       if (stage_needs_w(s + 2)) load_w(fresh_w, lchunk);
       advance_load();
     }
     const bool nxt = s + 1 < nstages;
     compute(s & 1, held_a, held_w, nxt, nxt && stage_needs_w(s + 1));
     if (chunk == a.nchunks - 1) {
-      if (!(a.dbg & 2)) epilogue(tile);
+      epilogue(tile);
       zero_acc();
     }
     __syncthreads();
@@ -339,7 +337,6 @@ static int launch_hconv_t(const HconvArgs& a_in, hipStream_t s, const char** nam
   HconvArgs a = a_in;
   a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
   a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
-  a.dbg = getenv("HCONV_DBG") ? atoi(getenv("HCONV_DBG")) : 0;
   const bool bighalo = a.HR > kHconvMaxHalo;    // the larger halo buffer leaves LDS room for 32 channels
   const int bn = (a.N % 64 == 0 && !bighalo) ? 64 : (a.N % 32 == 0) ? 32 : 16;
   const int ny = a.N / bn;
