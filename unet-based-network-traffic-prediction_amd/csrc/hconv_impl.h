@@ -47,6 +47,48 @@ constexpr int kHconvBigHalo = 768;      // 4x4 images (16 per tile, pitch 8): ne
 // slots {0-3, 8-11, 16-19, 24-27}, whose bit 2 is constant -- a 4-way conflict -- and bit 3 (the
 // halo row parity) is the one that spreads them.  A vertical tap shift of one row flips bit 3, so
 // that variant flips the chunk bit of the precomputed fragment address for odd ty.
+// Output-channel order inside a workgroup's BN = 16*TN channels.  MFMA row r of channel tile i is
+// channel 4*TN*(r>>2) + 4*i + (r&3), so the 4*TN accumulator values a lane holds for one pixel
+// (rows 4*(lane>>4)+q of every tile i) are 4*TN CONSECUTIVE channels: the epilogue writes them
+// with 16-byte stores, and the four lanes of a pixel cover one contiguous 2*BN-byte run.
+template <int TN> __device__ __forceinline__ int nmap(int i, int r) { return 4 * TN * (r >> 2) + 4 * i + (r & 3); }
+// Bank swizzle of the weight image rows (row = tap*BN + n): a 16-lane fragment read touches rows
+// {4*TN*g + 4*i + q}, g,q = 0..3; XORing the chunk with 2*(bit log2(4*TN) of the row) keeps every
+// 16-lane phase of the ds_read_b128 on 64 distinct banks.
+template <int TN> __device__ __forceinline__ int wswz(int row) {
+  constexpr int SH = TN == 4 ? 4 : (TN == 2 ? 3 : 2);
+  return ((row >> SH) & 1) << 1;
+}
+__device__ __forceinline__ void load_run(const float* p, float* v, int n) {
+  for (int k = 0; k < n; k += 4) { const f32x4_t t = *(const f32x4_t*)(p + k); v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3]; }
+}
+__device__ __forceinline__ void load_run(const __bf16* p, float* v, int n) {
+  if (n % 8 == 0) {
+    for (int k = 0; k < n; k += 8) {
+      const bf16x8_t t = *(const bf16x8_t*)(p + k);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k + e] = (float)t[e];
+    }
+  } else {
+    for (int k = 0; k < n; k += 4) { const f32x4_t t = load4f(p + k); v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3]; }
+  }
+}
+__device__ __forceinline__ void store_run(float* p, const float* v, int n) {
+  for (int k = 0; k < n; k += 4) *(f32x4_t*)(p + k) = f32x4_t{v[k], v[k + 1], v[k + 2], v[k + 3]};
+}
+__device__ __forceinline__ void store_run(__bf16* p, const float* v, int n) {
+  if (n % 8 == 0) {
+    for (int k = 0; k < n; k += 8) {
+      bf16x8_t t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (__bf16)v[k + e];
+      *(bf16x8_t*)(p + k) = t;
+    }
+  } else {
+    for (int k = 0; k < n; k += 4) store4f(p + k, f32x4_t{v[k], v[k + 1], v[k + 2], v[k + 3]});
+  }
+}
+
 template <bool ROWPAR> __device__ __forceinline__ int hswz(int hr) { return ROWPAR ? (hr >> 2) & 2 : (hr >> 1) & 2; }
 
 template <typename T, int TN, int MH, int TM>
@@ -141,14 +183,14 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   auto store_w_piece = [&](const w_regs_t& rw, int buf, int i) {
     char* Wt = smem + buf * STAGE + A_BYTES;
     const int id = t + NT * i, row = id >> 2, ch = id & 3;
-    if (row < 9 * BN) *(u32x4_t*)(Wt + row * 64 + ((ch ^ ((row >> 1) & 2)) << 4)) = rw[i];
+    if (row < 9 * BN) *(u32x4_t*)(Wt + row * 64 + ((ch ^ wswz<TN>(row)) << 4)) = rw[i];
   };
   auto store_w = [&](const w_regs_t& rw, int buf) {
     char* Wt = smem + buf * STAGE + A_BYTES;
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int id = t + NT * i, row = id >> 2, ch = id & 3;
-      if (row < 9 * BN) *(u32x4_t*)(Wt + row * 64 + ((ch ^ ((row >> 1) & 2)) << 4)) = rw[i];
+      if (row < 9 * BN) *(u32x4_t*)(Wt + row * 64 + ((ch ^ wswz<TN>(row)) << 4)) = rw[i];
     }
   };
 
@@ -167,10 +209,15 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
       const int hr = hrow + tx;
       paddr[j][tx] = hr * 64 + ((ch ^ hswz<ROWPAR>(hr)) << 4);
     }
-    out_off[j] = pl * a.out_cs + a.out_co + n0 + 4 * ch;
-    mask_off[j] = pl * a.mask_cs + a.mask_co + n0 + 4 * ch;
+    out_off[j] = pl * a.out_cs + a.out_co + n0 + 4 * TN * ch;
+    mask_off[j] = pl * a.mask_cs + a.mask_co + n0 + 4 * TN * ch;
   }
-  const int wfrag_off = A_BYTES + r16 * 64 + ((ch ^ ((r16 >> 1) & 2)) << 4);
+  int wfrag[TN];                   // this lane's weight-fragment address inside a tap's BN rows, per channel tile
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = nmap<TN>(i, r16);
+    wfrag[i] = A_BYTES + n * 64 + ((ch ^ wswz<TN>(n)) << 4);
+  }
   const int ty_bytes = a.pitch * 64;
 
   f32x4_t acc[TN][TM];
@@ -196,7 +243,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
 #pragma unroll
       for (int j = 0; j < TM; ++j) pf[set][j] = *(const frag_t*)(Sy + (paddr[j][tx] ^ flip));
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[set][i] = *(const frag_t*)(S + (tap * BN + i * 16) * 64 + wfrag_off);
+      for (int i = 0; i < TN; ++i) wf[set][i] = *(const frag_t*)(S + tap * BN * 64 + wfrag[i]);
     };
     constexpr int PIECES = A_IT + W_IT;
     read_tap(0, 0);
@@ -217,53 +264,52 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   };
   T* __restrict__ out = (T*)a.out;
   const T* __restrict__ mask = (const T*)a.mask;
-  // bias of this lane's 4 channels per channel tile, read once (clamped unconditional loads)
-  f32x4_t biasv[TN];
+  // bias of this lane's 4*TN consecutive channels, read once (clamped unconditional loads)
+  constexpr int CPL = 4 * TN;
+  float biasv[CPL];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = n0 + i * 16 + 4 * ch + q;
-      float b = 0.f;
-      if (a.bias != nullptr) {
-        b = a.bias[n < a.n_real ? n : 0];
-        if (n >= a.n_real) b = 0.f;
-      }
-      biasv[i][q] = b;
+  for (int k = 0; k < CPL; ++k) {
+    const int n = n0 + CPL * ch + k;
+    float b = 0.f;
+    if (a.bias != nullptr) {
+      b = a.bias[n < a.n_real ? n : 0];
+      if (n >= a.n_real) b = 0.f;
     }
+    biasv[k] = b;
   }
   auto epilogue = [&](int tile) {
     T* otile = out + (int64_t)tile * BM * a.out_cs;
     if (mask != nullptr) {
       // all mask loads first, then all stores: interleaved, every store would wait for its load
       const T* mtile = mask + (int64_t)tile * BM * a.mask_cs;
-      f32x4_t mv[TM][TN];
+      float mv[TM][CPL];
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+      for (int j = 0; j < TM; ++j) load_run(mtile + mask_off[j], mv[j], CPL);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) mv[j][i] = load4f(mtile + mask_off[j] + i * 16);
+      for (int j = 0; j < TM; ++j) {
+        float v[CPL];
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          f32x4_t v = acc[i][j] + biasv[i];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = mv[j][i][q] > 0.f ? v[q] : 0.f;
-          store4f(otile + out_off[j] + i * 16, v);
-        }
+          for (int q = 0; q < 4; ++q) {
+            const float x = acc[i][j][q] + biasv[4 * i + q];
+            v[4 * i + q] = mv[j][4 * i + q] > 0.f ? x : 0.f;
+          }
+        store_run(otile + out_off[j], v, CPL);
+      }
       return;
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
+      float v[CPL];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        f32x4_t v = acc[i][j] + biasv[i];
-        if (a.relu) {
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const float x = acc[i][j][q] + biasv[4 * i + q];
+          v[4 * i + q] = (a.relu && !(x > 0.f)) ? 0.f : x;
         }
-        store4f(otile + out_off[j] + i * 16, v);
-      }
+      store_run(otile + out_off[j], v, CPL);
     }
   };
 
