@@ -246,7 +246,7 @@ WgradLayout convt_wgrad_layout(int B, int H, int W, int Cin, int Cout, int dtype
 }
 int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
                       float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int split,
-                      int Cout, int dtype, hipStream_t s, const char** name, int phase) {
+                      int Cout, int dtype, hipStream_t s, const char** name, FinJobs* defer) {
   const WgradLayout l = conv3x3_wgrad_layout(B, H, W, Cin, split, Cout, dtype);
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "conv3x3_wgrad: workspace too small");
   if (l.halo) {
@@ -261,9 +261,12 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
     MI_REQUIRE(h.zero != nullptr, "conv3x3_wgrad: cannot resolve the zero page on this device");
     MI_REQUIRE(x && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && xcs % 16 == 0 && xco % 16 == 0 &&
                    ycs % 16 == 0 && yco % 16 == 0, "conv3x3_wgrad: operands must be 16-byte aligned views");
-    int rc = (phase & 1) ? launch_hwgrad_bf16(h, s, name) : MI_OK;
-    if (rc || !(phase & 2)) return rc;
-    return launch_finalize_conv3(h.part, h.rowsum, l.slabs, h.Na, h.Cb, Cout, Cin, split, dW, db, alpha, beta, s);
+    int rc = launch_hwgrad_bf16(h, s, name);
+    if (rc) return rc;
+    FinJobs one{};
+    FinJobs& J = defer ? *defer : one;
+    rc = fin_jobs_add_conv3(J, h.part, h.rowsum, l.slabs, h.Na, h.Cb, Cout, Cin, split, dW, db, alpha, beta);
+    return rc || defer ? rc : launch_finalize_multi(one, s);
   }
   WgradArgs a{};
   a.a = dy; a.a_cs = ycs; a.a_co = yco; a.Na = pad_ch(Cout);
@@ -276,13 +279,16 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
   a.splits = l.splits; a.pix_per_split = l.pps;
   a.M = B * H * W;
   a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
-  int rc = (phase & 1) ? launch_wgrad(a, dtype, s, name) : MI_OK;
-  if (rc || !(phase & 2)) return rc;
-  return launch_finalize_conv3(a.part, a.rowsum, l.splits, a.Na, a.Cb, Cout, Cin, split, dW, db, alpha, beta, s);
+  int rc = launch_wgrad(a, dtype, s, name);
+  if (rc) return rc;
+  FinJobs one{};
+  FinJobs& J = defer ? *defer : one;
+  rc = fin_jobs_add_conv3(J, a.part, a.rowsum, l.splits, a.Na, a.Cb, Cout, Cin, split, dW, db, alpha, beta);
+  return rc || defer ? rc : launch_finalize_multi(one, s);
 }
 int run_convt_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
                     float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int Cout,
-                    int dtype, hipStream_t s, const char** name, int phase) {
+                    int dtype, hipStream_t s, const char** name, FinJobs* defer) {
   const WgradLayout l = convt_wgrad_layout(B, H, W, Cin, Cout, dtype);
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "convt2x2_wgrad: workspace too small");
   WgradArgs a{};
@@ -295,9 +301,12 @@ int run_convt_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, in
   a.splits = l.splits; a.pix_per_split = l.pps;
   a.M = B * H * W;
   a.divHW = make_fastdiv(H * W); a.divW = make_fastdiv(W);
-  int rc = (phase & 1) ? launch_wgrad(a, dtype, s, name) : MI_OK;
-  if (rc || !(phase & 2)) return rc;
-  return launch_finalize_convt(a.part, a.colsum, l.splits, a.Na, a.Cb, Cin, Cout, dW, db, alpha, beta, s);
+  int rc = launch_wgrad(a, dtype, s, name);
+  if (rc) return rc;
+  FinJobs one{};
+  FinJobs& J = defer ? *defer : one;
+  rc = fin_jobs_add_convt(J, a.part, a.colsum, l.splits, a.Na, a.Cb, Cin, Cout, dW, db, alpha, beta);
+  return rc || defer ? rc : launch_finalize_multi(one, s);
 }
 
 }  // namespace mi
@@ -358,7 +367,7 @@ int mi_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, i
                      int Cout, int dtype, mi_stream s) {
   MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "conv3x3_wgrad: bad arguments");
   return run_conv3x3_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, split, Cout,
-                           dtype, (hipStream_t)s, nullptr, 3);
+                           dtype, (hipStream_t)s, nullptr, nullptr);
 }
 
 int mi_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C, int dtype,
@@ -395,7 +404,7 @@ int mi_convt2x2_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
                       int dtype, mi_stream s) {
   MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "convt2x2_wgrad: bad arguments");
   return run_convt_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, Cout, dtype,
-                         (hipStream_t)s, nullptr, 3);
+                         (hipStream_t)s, nullptr, nullptr);
 }
 
 int mi_conv1x1_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,

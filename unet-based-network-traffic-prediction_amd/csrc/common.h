@@ -119,13 +119,26 @@ int hwgrad_slabs_per_split(int Na);
 int launch_hwgrad_bf16(const HwgradArgs& a, hipStream_t s, const char** name);
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
 int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
-// dW (Cout,Cin,3,3), db from partials laid out [z][Npad][9*Cp] / rowsum [z][Npad]
-int launch_finalize_conv3(const float* part, const float* rowsum, int splits, int Npad, int Cp,
-                          int Cout, int Cin, int split, float* dW, float* db, float alpha, float beta,
-                          hipStream_t s);
-// dW (Cin,Cout,2,2), db from partials [z][Cp_in][4*Npad] / colsum [z][4*Npad]
-int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad,
-                          int Cin, int Cout, float* dW, float* db, float alpha, float beta, hipStream_t s);
+// Fixed-order combination of the partials into dW / db, several layers per launch (the table is
+// passed by value in the kernel arguments).
+//   conv3: dW (Cout,Cin,3,3), db from partials [z][Npad][9*Cp] / row sums [z][Npad]
+//   convT: dW (Cin,Cout,2,2), db from partials [z][Cp][4*Npad] / column sums [z][4*Npad] (Cp = padded Cin)
+enum FinKind { FIN_CONV3 = 0, FIN_CONVT = 1, FIN_CONV3_WIDE = 2 };
+constexpr int kMaxFinJobs = 8;
+struct FinJob {
+  int kind;
+  const float* part; const float* sum;
+  int splits, Npad, Cp, Cout, Cin, split, G;
+  float* dW; float* db;
+  float alpha, beta;
+  int block_end;                         // running count of workgroups up to and including this job
+};
+struct FinJobs { int n; FinJob job[kMaxFinJobs]; };
+int fin_jobs_add_conv3(FinJobs& J, const float* part, const float* rowsum, int splits, int Npad, int Cp, int Cout,
+                       int Cin, int split, float* dW, float* db, float alpha, float beta);
+int fin_jobs_add_convt(FinJobs& J, const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin,
+                       int Cout, float* dW, float* db, float alpha, float beta);
+int launch_finalize_multi(const FinJobs& J, hipStream_t s);
 
 // ---------------------------------------------------------------- pointwise (pointwise.hip)
 int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W,

@@ -31,9 +31,9 @@ IgemmArgs conv3x3_dgrad_args(const void*, int, int, const void*, void*, int, int
 IgemmArgs convt_fwd_args(const void*, int, int, const void*, const float*, void*, int, int, int, int, int, int, int);
 IgemmArgs convt_dgrad_args(const void*, int, int, const void*, void*, int, int, const void*, int, int, int, int, int, int, int);
 int run_conv3x3_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
-                      int, int, int, int, int, hipStream_t, const char**, int);
+                      int, int, int, int, int, hipStream_t, const char**, FinJobs*);
 int run_convt_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
-                    int, int, int, int, hipStream_t, const char**, int);
+                    int, int, int, int, hipStream_t, const char**, FinJobs*);
 
 enum LayerKind { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2 };
 struct Layer {
@@ -41,6 +41,7 @@ struct Layer {
   int kind, cin, cout, split;
   int64_t w_off, b_off;      // element offsets into the flat fp32 parameter buffer
   size_t wf_off, wb_off;     // byte offsets of the packed operands in the workspace
+  size_t part_off, part_bytes;   // the layer's own region for weight-gradient partials
 };
 struct Tensor {              // an allocation in the workspace
   std::string name;
@@ -132,6 +133,7 @@ struct Run {   // per-call context
   int rc;
   // weight-gradient launches of the current backward segment, issued together by flush_wgrads()
   std::vector<std::function<int(hipStream_t)>> deferred;
+  FinJobs fin{};   // their combine jobs, one launch per segment
   View view(const std::string& name, int coff = 0) const {
     const int id = P->tensor_id(name);
     const Tensor& t = P->tensors[id];
@@ -245,32 +247,39 @@ int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float a
     Run& r = *rp;
     const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
     const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
-    for (int phase = 1; phase <= 2; ++phase) {
-      Scope sc(r.P, ws, phase == 1 ? lab.c_str() : (lab + ".reduce").c_str(), phase == 1 ? fl : 0.0,
-               phase == 1 ? by : 4.0 * l.cout * l.cin * 9);
-      const char* k = phase == 1 ? nullptr : "finalize_conv3";
-      int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
-                                 r.ws + r.P->scratch_off, r.P->scratch_bytes, B, H, W, l.cin, l.split, l.cout,
-                                 r.P->d.dtype, ws, phase == 1 ? &k : nullptr, phase);
-      sc.kernel(k);
-      if (rc) return rc;
-    }
-    return MI_OK;
+    Scope sc(r.P, ws, lab.c_str(), fl, by);
+    const char* k = nullptr;
+    int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
+                               r.ws + l.part_off, l.part_bytes, B, H, W, l.cin, l.split, l.cout, r.P->d.dtype, ws, &k,
+                               &r.fin);
+    sc.kernel(k);
+    return rc;
   });
   return MI_OK;
 }
-// Issues the deferred weight-gradient launches of a segment on the side stream behind ONE fork:
-// an event record + stream wait per layer costs more host time than the launches themselves.
-int flush_wgrads(Run& r) {
+// Issues the deferred weight-gradient launches of a segment on the side stream behind ONE fork
+// (an event record + stream wait per layer costs more host time than the launches themselves),
+// then ONE launch that combines the partials of all of them: every layer has its own partial
+// region, so the sums need not sit between the weight-gradient kernels as dependent launches.
+int flush_wgrads(Run& r, int seg) {
   if (r.deferred.empty()) return MI_OK;
   hipStream_t ws = fork_side(r);
   int rc = MI_OK;
+  r.fin.n = 0;
   for (auto& f : r.deferred) {
     rc = f(ws);
     if (rc) break;
   }
   r.deferred.clear();
-  return rc;
+  if (rc) return rc;
+  double bytes = 0;
+  for (int i = 0; i < r.fin.n; ++i) {
+    const FinJob& q = r.fin.job[i];
+    bytes += 4.0 * (q.kind == FIN_CONVT ? 4.0 * q.Cin * q.Cout : 9.0 * q.Cin * q.Cout) * (q.splits + 1);
+  }
+  Scope sc(r.P, ws, ("seg" + std::to_string(seg) + ".wgrad.reduce").c_str(), 0.0, bytes);
+  sc.kernel("finalize");
+  return launch_finalize_multi(r.fin, ws);
 }
 
 // Launch-sequence graphs.  A training step is ~110 dependent launches of 10-30 us kernels: issued
@@ -474,11 +483,13 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     add_tensor(P, "g.u2." + std::to_string(j), B, P->h[l], P->w[l], f, 0, cur);
   }
   if (P->out_resize) add_tensor(P, "g.pred0", B, d.height, d.width, d.out_channels, 1, cur);
-  // scratch for weight-gradient partials (layers run one after another on one stream)
-  size_t scratch = head_ws_bytes(d.features[0], d.out_channels);
+  // weight-gradient partials: the head's scratch, then one region per layer (the partials of a
+  // backward segment are combined by one launch after all its weight-gradient kernels)
+  P->scratch_off = cur; P->scratch_bytes = align_up(head_ws_bytes(d.features[0], d.out_channels), 256);
+  cur += P->scratch_bytes;
   {
     int lvl_h, lvl_w;
-    for (const auto& l : P->layers) {
+    for (auto& l : P->layers) {
       // spatial size of the layer's OUTPUT grid for conv3 / INPUT grid for convT
       if (l.prefix.rfind("downs.", 0) == 0) { const int i = std::stoi(l.prefix.substr(6)); lvl_h = P->h[i]; lvl_w = P->w[i]; }
       else if (l.prefix.rfind("bottleneck.", 0) == 0) { lvl_h = P->h[L]; lvl_w = P->w[L]; }
@@ -488,11 +499,10 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
       } else continue;
       const size_t need = l.kind == K_CONV3 ? mi_conv3x3_wgrad_ws_bytes(B, lvl_h, lvl_w, l.cin, l.split, l.cout, d.dtype)
                                             : mi_convt2x2_wgrad_ws_bytes(B, lvl_h, lvl_w, l.cin, l.cout, d.dtype);
-      if (need > scratch) scratch = need;
+      l.part_off = cur; l.part_bytes = align_up(need, 256);
+      cur += l.part_bytes;
     }
   }
-  P->scratch_off = cur; P->scratch_bytes = align_up(scratch, 256);
-  cur += P->scratch_bytes;
   P->ws_bytes = cur;
 
   // ---- named views for parity checks (names follow the reference's module paths)
@@ -811,17 +821,13 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
           const Layer& up = *upp;
           Run& r = *rp;
           const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
-          for (int phase = 1; phase <= 2; ++phase) {
-            Scope sc(P, ws, (up.prefix + (phase == 1 ? ".wgrad" : ".wgrad.reduce")).c_str(), phase == 1 ? fl : 0.0,
-                     phase == 1 ? (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P) : 16.0 * up.cin * up.cout);
-            const char* k = phase == 1 ? nullptr : "finalize_convt";
-            int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
-                                     alpha, beta, r.ws + P->scratch_off, P->scratch_bytes, B, hin, win, up.cin, up.cout, dt,
-                                     ws, phase == 1 ? &k : nullptr, phase);
-            sc.kernel(k);
-            if (rc) return rc;
-          }
-          return MI_OK;
+          Scope sc(P, ws, (up.prefix + ".wgrad").c_str(), fl, (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P));
+          const char* k = nullptr;
+          int rc = run_convt_wgrad(prev.p, prev.cs, prev.co, dyT.p, dyT.cs, dyT.co, grads + up.w_off, grads + up.b_off,
+                                   alpha, beta, r.ws + up.part_off, up.part_bytes, B, hin, win, up.cin, up.cout, dt, ws, &k,
+                                   &r.fin);
+          sc.kernel(k);
+          return rc;
         });
       }
       {
@@ -882,7 +888,7 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
         RUN(launch_nhwc_to_nchw(gx.p, gx.cs, 0, dx_nchw, B, d.in_channels, H, W, dt, r.s));
       }
     }
-    RUN(flush_wgrads(r));
+    RUN(flush_wgrads(r, seg));
   }
   return (phases & PH_BODY) ? join_side(r) : MI_OK;
 }

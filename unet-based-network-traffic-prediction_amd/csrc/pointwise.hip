@@ -950,67 +950,63 @@ static inline int finalize_groups(int splits, int64_t outputs) {
   while (g < 16 && g < splits && outputs * (2 * g) <= 2048ll * 256) g *= 2;
   return g;
 }
-__global__ __launch_bounds__(256) void finalize_conv3_kernel(const float* __restrict__ part, const float* __restrict__ rowsum,
-                                                              int splits, int Npad, int Cp, int Cout, int Cin, int split,
-                                                              float* __restrict__ dW, float* __restrict__ db, float alpha,
-                                                              float beta, int G) {
-  __shared__ float sh[256];
+// The three bodies below run as workgroup `vb` of `nb` of their job (one launch serves several layers).
+__device__ __forceinline__ void finalize_conv3_body(const FinJob& q, int vb, int nb, float* sh) {
+  const int Cp = q.Cp, Cout = q.Cout, G = q.G;
   const int K = 9 * Cp;
-  const int split_pad = pad_ch(split);
+  const int split_pad = pad_ch(q.split);
   const int64_t total = (int64_t)Cout * K + Cout;
   const int cols = 256 / G;
   const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
-  for (int64_t base = (int64_t)blockIdx.x * cols; base < total; base += (int64_t)gridDim.x * cols) {
+  for (int64_t base = (int64_t)vb * cols; base < total; base += (int64_t)nb * cols) {
     const int64_t i = base + o;
     float v = 0.f;
     int co = 0, k = 0;
     const bool is_w = i < (int64_t)Cout * K, live = i < total;
     if (live) {
       if (is_w) {
-        co = (int)(i / K); k = (int)(i % K);
-        v = sum_splits(part + (int64_t)co * K + k, (int64_t)Npad * K, zg, splits, G);
+        co = (int)((uint32_t)i / (uint32_t)K); k = (int)((uint32_t)i - (uint32_t)co * (uint32_t)K);
+        v = sum_splits(q.part + (int64_t)co * K + k, (int64_t)q.Npad * K, zg, q.splits, G);
       } else {
         co = (int)(i - (int64_t)Cout * K);
-        if (rowsum) v = sum_splits(rowsum + co, Npad, zg, splits, G);
+        if (q.sum) v = sum_splits(q.sum + co, q.Npad, zg, q.splits, G);
       }
     }
     const float s = combine_groups(v, sh, G, cols);
     if (zg == 0 && live) {
       if (is_w) {
         const int tap = k / Cp, pos = k % Cp;
-        const int ci = unpos(pos, Cin, split, split_pad);
+        const int ci = unpos(pos, q.Cin, q.split, split_pad);
         if (ci >= 0) {
-          float* out = dW + ((int64_t)co * Cin + ci) * 9 + tap;
-          *out = alpha * s + (beta != 0.f ? beta * *out : 0.f);
+          float* out = q.dW + ((int64_t)co * q.Cin + ci) * 9 + tap;
+          *out = q.alpha * s + (q.beta != 0.f ? q.beta * *out : 0.f);
         }
-      } else if (db != nullptr) {
-        db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+      } else if (q.db != nullptr) {
+        q.db[co] = q.alpha * s + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
       }
     }
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __restrict__ part, const float* __restrict__ colsum,
-                                                              int splits, int Cp_in, int Npad, int Cin, int Cout,
-                                                              float* __restrict__ dW, float* __restrict__ db, float alpha,
-                                                              float beta, int G) {
-  __shared__ float sh[256];
+// Transposed conv: partials [z][Cp][4*Npad], column sums [z][4*Npad]; Cp = padded input channels.
+__device__ __forceinline__ void finalize_convt_body(const FinJob& q, int vb, int nb, float* sh) {
+  const int Npad = q.Npad, Cin = q.Cin, Cout = q.Cout, G = q.G;
   const int K = 4 * Npad;
   const int64_t total = (int64_t)Cin * K + Cout;
   const int cols = 256 / G;
   const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
-  for (int64_t base = (int64_t)blockIdx.x * cols; base < total; base += (int64_t)gridDim.x * cols) {
+  for (int64_t base = (int64_t)vb * cols; base < total; base += (int64_t)nb * cols) {
     const int64_t i = base + o;
     float v = 0.f;
     int ci = 0, k = 0;
     const bool is_w = i < (int64_t)Cin * K, live = i < total;
     if (live) {
       if (is_w) {
-        ci = (int)(i / K); k = (int)(i % K);
-        v = sum_splits(part + (int64_t)ci * K + k, (int64_t)Cp_in * K, zg, splits, G);
-      } else if (colsum) {
+        ci = (int)((uint32_t)i / (uint32_t)K); k = (int)((uint32_t)i - (uint32_t)ci * (uint32_t)K);
+        v = sum_splits(q.part + (int64_t)ci * K + k, (int64_t)q.Cp * K, zg, q.splits, G);
+      } else if (q.sum) {
         const int co = (int)(i - (int64_t)Cin * K);
-        for (int g = 0; g < 4; ++g) v += sum_splits(colsum + g * Npad + co, K, zg, splits, G);
+        for (int g = 0; g < 4; ++g) v += sum_splits(q.sum + g * Npad + co, K, zg, q.splits, G);
       }
     }
     const float s = combine_groups(v, sh, G, cols);
@@ -1018,12 +1014,12 @@ __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __rest
       if (is_w) {
         const int g = k / Npad, co = k % Npad;
         if (co < Cout) {
-          float* out = dW + ((int64_t)ci * Cout + co) * 4 + g;
-          *out = alpha * s + (beta != 0.f ? beta * *out : 0.f);
+          float* out = q.dW + ((int64_t)ci * Cout + co) * 4 + g;
+          *out = q.alpha * s + (q.beta != 0.f ? q.beta * *out : 0.f);
         }
-      } else if (db != nullptr) {
+      } else if (q.db != nullptr) {
         const int co = (int)(i - (int64_t)Cin * K);
-        db[co] = alpha * s + (beta != 0.f ? beta * db[co] : 0.f);
+        q.db[co] = q.alpha * s + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
       }
     }
     __syncthreads();
@@ -1032,21 +1028,18 @@ __global__ __launch_bounds__(256) void finalize_convt_kernel(const float* __rest
 // Few splits, large layers: one workgroup per (output channel, 64 packed input positions).  The
 // partial columns are read tap by tap (coalesced), transposed through LDS, and written as one
 // contiguous run of dW[co][ci][3][3].
-__global__ __launch_bounds__(256) void finalize_conv3_wide_kernel(const float* __restrict__ part,
-                                                                   const float* __restrict__ rowsum, int splits,
-                                                                   int Npad, int Cp, int Cout, int Cin, int split,
-                                                                   float* __restrict__ dW, float* __restrict__ db,
-                                                                   float alpha, float beta) {
-  __shared__ float sh[9 * 64];
+__device__ __forceinline__ void finalize_conv3_wide_body(const FinJob& q, int vb, float* sh) {
+  const int Cp = q.Cp, splits = q.splits;
   const int K = 9 * Cp;
-  const int co = blockIdx.x, pos0 = blockIdx.y * 64;
-  const int split_pad = pad_ch(split);
+  const int ny = (Cp + 63) / 64;
+  const int co = vb / ny, pos0 = (vb - co * ny) * 64;
+  const int split_pad = pad_ch(q.split);
   for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
     const int tap = idx >> 6, o = idx & 63;
     float v = 0.f;
     if (pos0 + o < Cp) {
-      const float* p = part + (int64_t)co * K + tap * Cp + pos0 + o;
-      for (int z = 0; z < splits; ++z) v += p[(int64_t)z * Npad * K];
+      const float* p = q.part + (int64_t)co * K + tap * Cp + pos0 + o;
+      for (int z = 0; z < splits; ++z) v += p[(int64_t)z * q.Npad * K];
     }
     sh[idx] = v;
   }
@@ -1054,38 +1047,65 @@ __global__ __launch_bounds__(256) void finalize_conv3_wide_kernel(const float* _
   for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
     const int cl = idx / 9, tap = idx - cl * 9;
     if (pos0 + cl >= Cp) continue;
-    const int ci = unpos(pos0 + cl, Cin, split, split_pad);
+    const int ci = unpos(pos0 + cl, q.Cin, q.split, split_pad);
     if (ci < 0) continue;
-    float* out = dW + ((int64_t)co * Cin + ci) * 9 + tap;
-    *out = alpha * sh[tap * 64 + cl] + (beta != 0.f ? beta * *out : 0.f);
+    float* out = q.dW + ((int64_t)co * q.Cin + ci) * 9 + tap;
+    *out = q.alpha * sh[tap * 64 + cl] + (q.beta != 0.f ? q.beta * *out : 0.f);
   }
-  if (blockIdx.y == 0 && threadIdx.x == 0 && db != nullptr) {
+  if (pos0 == 0 && threadIdx.x == 0 && q.db != nullptr) {
     float v = 0.f;
-    if (rowsum)
-      for (int z = 0; z < splits; ++z) v += rowsum[(int64_t)z * Npad + co];
-    db[co] = alpha * v + (beta != 0.f ? beta * db[co] : 0.f);
+    if (q.sum)
+      for (int z = 0; z < splits; ++z) v += q.sum[(int64_t)z * q.Npad + co];
+    q.db[co] = q.alpha * v + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
   }
 }
-int launch_finalize_conv3(const float* part, const float* rowsum, int splits, int Npad, int Cp, int Cout, int Cin,
-                          int split, float* dW, float* db, float alpha, float beta, hipStream_t s) {
+// One launch for all the layers of a backward segment: a chain of small dependent launches costs
+// more in dispatch gaps than the sums themselves.
+__global__ __launch_bounds__(256) void finalize_multi_kernel(const FinJobs J) {
+  __shared__ float sh[9 * 64];
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.job[j].block_end) ++j;
+  const FinJob& q = J.job[j];
+  const int first = j ? J.job[j - 1].block_end : 0;
+  const int vb = (int)blockIdx.x - first, nb = q.block_end - first;
+  if (q.kind == FIN_CONV3) finalize_conv3_body(q, vb, nb, sh);
+  else if (q.kind == FIN_CONVT) finalize_convt_body(q, vb, nb, sh);
+  else finalize_conv3_wide_body(q, vb, sh);
+}
+static int fin_push(FinJobs& J, FinJob q, int blocks) {
+  if (J.n >= kMaxFinJobs) return fail(MI_EINVAL, "finalize: too many jobs in one launch");
+  q.block_end = (J.n ? J.job[J.n - 1].block_end : 0) + blocks;
+  J.job[J.n++] = q;
+  return MI_OK;
+}
+int fin_jobs_add_conv3(FinJobs& J, const float* part, const float* rowsum, int splits, int Npad, int Cp, int Cout, int Cin,
+                       int split, float* dW, float* db, float alpha, float beta) {
+  MI_REQUIRE((int64_t)Cout * 9 * Cp + Cout < (1ll << 31), "finalize: layer too large");
+  FinJob q{};
+  q.part = part; q.sum = rowsum; q.splits = splits; q.Npad = Npad; q.Cp = Cp; q.Cout = Cout; q.Cin = Cin; q.split = split;
+  q.dW = dW; q.db = db; q.alpha = alpha; q.beta = beta;
   if (splits <= 8 && (int64_t)Cout * Cp >= 64 * 256) {
-    hipLaunchKernelGGL(finalize_conv3_wide_kernel, dim3(Cout, (Cp + 63) / 64), dim3(256), 0, s, part, rowsum, splits,
-                       Npad, Cp, Cout, Cin, split, dW, db, alpha, beta);
-    return check_hip(hipGetLastError(), "finalize_conv3");
+    q.kind = FIN_CONV3_WIDE; q.G = 1;
+    return fin_push(J, q, Cout * ((Cp + 63) / 64));
   }
   const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
-  const int G = finalize_groups(splits, total);
-  hipLaunchKernelGGL(finalize_conv3_kernel, dim3(grid_for(total, 256 / G, 8192)), dim3(256), 0, s, part, rowsum, splits, Npad,
-                     Cp, Cout, Cin, split, dW, db, alpha, beta, G);
-  return check_hip(hipGetLastError(), "finalize_conv3");
+  q.kind = FIN_CONV3; q.G = finalize_groups(splits, total);
+  return fin_push(J, q, grid_for(total, 256 / q.G, 8192));
 }
-int launch_finalize_convt(const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin, int Cout,
-                          float* dW, float* db, float alpha, float beta, hipStream_t s) {
+int fin_jobs_add_convt(FinJobs& J, const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin,
+                       int Cout, float* dW, float* db, float alpha, float beta) {
   const int64_t total = (int64_t)Cin * 4 * Npad + Cout;
-  const int G = finalize_groups(splits, total);
-  hipLaunchKernelGGL(finalize_convt_kernel, dim3(grid_for(total, 256 / G, 8192)), dim3(256), 0, s, part, colsum, splits, Cp_in,
-                     Npad, Cin, Cout, dW, db, alpha, beta, G);
-  return check_hip(hipGetLastError(), "finalize_convt");
+  MI_REQUIRE(total < (1ll << 31), "finalize: layer too large");
+  FinJob q{};
+  q.kind = FIN_CONVT; q.part = part; q.sum = colsum; q.splits = splits; q.Npad = Npad; q.Cp = Cp_in; q.Cout = Cout; q.Cin = Cin;
+  q.dW = dW; q.db = db; q.alpha = alpha; q.beta = beta;
+  q.G = finalize_groups(splits, total);
+  return fin_push(J, q, grid_for(total, 256 / q.G, 8192));
+}
+int launch_finalize_multi(const FinJobs& J, hipStream_t s) {
+  if (J.n == 0) return MI_OK;
+  hipLaunchKernelGGL(finalize_multi_kernel, dim3(J.job[J.n - 1].block_end), dim3(256), 0, s, J);
+  return check_hip(hipGetLastError(), "finalize");
 }
 
 }  // namespace mi
