@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--layers-out", default="", help="write per-launch records of the last instrumented step here")
     ap.add_argument("--bucket-mb", type=float, default=8.0, help="gradient all-reduce bucket size (MiB), N > 1 only")
     ap.add_argument("--stock-optim", action="store_true", help="torch.optim.Adam + nn.MSELoss instead of the fused ones")
+    ap.add_argument("--input-pipeline", action="store_true",
+                    help="gather every step's batch from a device-resident series (SeriesWindows) inside the timed region")
     args = ap.parse_args()
 
     import unet_amd
@@ -132,6 +134,15 @@ def main():
     Y = unet_amd.shard_batch(Yg, rank, world).to(dev)
     del Xg, Yg
 
+    pipe = None
+    if args.input_pipeline:
+        if cout != 1:
+            sys.exit("bench: --input-pipeline needs a one-channel target (the series has one feature)")
+        import numpy as np
+        rng = np.random.RandomState(1 + rank)
+        sw = unet_amd.SeriesWindows(np.abs(np.cumsum(rng.randn(H * W * 2 + 200000)) * 30 + 2000), H, W, H, W, 0, 1, context=cin, device=dev)
+        pipe = (sw, sw.to_device_ids(rng.randint(cin - 1, sw.num_windows, size=batch * 64)), [0])
+
     force_dp = os.environ.get("UNET_TM_FORCE_DP") == "1"      # one-rank rehearsal of the RCCL path
     reducer = unet_amd.GradientReducer(bucket_bytes=int(args.bucket_mb * (1 << 20)), force=force_dp).attach(model) if (world > 1 or force_dp) else None
     if world > 1 or force_dp:
@@ -144,6 +155,11 @@ def main():
     loss_acc = torch.zeros((), device=dev)
 
     def step():
+        if pipe is not None:                   # this step's batch: one gather kernel, no host copy
+            sw, ids, cursor = pipe
+            lo = cursor[0] % 64 * batch
+            cursor[0] += 1
+            sw.batch(ids[lo:lo + batch], out=(X, Y))
         if train:
             pred = model(X)
             loss = crit(pred, Y)
@@ -227,7 +243,8 @@ def main():
             "metric": "U-Net train TMs/sec (fwd+bwd)" if train else "U-Net inference TMs/sec",
             "value": round(value, 1), "unit": "TMs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(host_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype,
+            "data": "synthetic series, batch gathered on the device every step" if pipe is not None else "synthetic",
             "config": {"workload": args.workload, "in_channels": cin, "out_channels": cout, "features": list(feats),
                        "height": H, "width": W, "per_gpu_batch": batch, "global_batch": batch * world,
                        "step": "fwd+MSE+zero_grad+bwd+Adam" if train else "fwd (no_grad)",

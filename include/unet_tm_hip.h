@@ -171,6 +171,29 @@ int mi_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy, int
 int mi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, mi_stream s);
 
+/* ------------------------------------------------------------------ F2: input pipeline */
+/* The raw series (float64, as pandas reads it: dataset.py:316-323) stays in device memory and
+ * batches are gathered from it; nothing image-shaped crosses PCIe.
+ * mi_series_minmax: out2 (device, 2 doubles) = { nanmin, nanmax } of the series, the statistics
+ *   MinMaxScaler.fit keeps (dataset.py:326-327).  ws: mi_series_minmax_ws_bytes().
+ * mi_window_count: number N of (input, target) window pairs, or -1 with the reference's
+ *   ValueError text in mi_last_error() (utils/image_transform.py:27-44).
+ * mi_window_batch: for b < B, with t = targets[b] the ORIGINAL window index of the sample's target
+ *   (K-1 <= t < N, device int64):
+ *     x[b][k][i][j] = norm(series[(t-K+1+k)*stride + i*W_in + j])                  k < K
+ *     y[b][i][j]    = norm(series[t*stride + H_in*W_in - overlap_len + i*W_out + j])
+ *   norm(v) = float32(v*scale + offset), two rounded float64 operations, i.e. exactly
+ *   MinMaxScaler.transform followed by the float32 cast of utils/image_transform.py:63-64.
+ *   x is (B,K,H_in,W_in): the K context windows of dataset.py:176-183 as channels; K = 1 gives the
+ *   single windows the reference feeds its U-Net.  y is (B,1,H_out,W_out) (dataset.py:221-223).
+ *   Positions outside the series (an invalid target index) read as 0. */
+size_t mi_series_minmax_ws_bytes(void);
+int mi_series_minmax(const double* series, int64_t n, double* out2, void* ws, size_t ws_bytes, mi_stream s);
+int64_t mi_window_count(int64_t n, int H_in, int W_in, int H_out, int W_out, int overlap_len, int stride);
+int mi_window_batch(const double* series, int64_t n, const int64_t* targets, int B, int K,
+                    int H_in, int W_in, int H_out, int W_out, int overlap_len, int stride,
+                    double scale, double offset, float* x, float* y, mi_stream s);
+
 /* ------------------------------------------------------------------ A7: whole-network plan */
 /* The orchestration of UNet.forward (models/unet2d.py:61-102) and of its autograd
  * backward as one launch sequence per call.  A plan is immutable shape metadata. */

@@ -53,6 +53,10 @@ SIGNATURES = {
     "mi_bilinear_fwd": (_i, [_p] + [_i64] * 4 + [_i, _p] + [_i64] * 4 + [_i] + [_i] * 6 + [_p]),
     "mi_bilinear_bwd": (_i, [_p] + [_i64] * 4 + [_i, _p] + [_i64] * 4 + [_i] + [_i] * 6 + [_p]),
     "mi_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p]),
+    "mi_series_minmax_ws_bytes": (_sz, []),
+    "mi_series_minmax": (_i, [_p, _i64, _p, _p, _sz, _p]),
+    "mi_window_count": (_i64, [_i64, _i, _i, _i, _i, _i, _i]),
+    "mi_window_batch": (_i, [_p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, C.c_double, C.c_double, _p, _p, _p]),
     "mi_unet_plan_create": (_i, [C.POINTER(UNetDesc), C.POINTER(_p)]),
     "mi_unet_plan_destroy": (None, [_p]),
     "mi_unet_plan_workspace_bytes": (_sz, [_p]),
