@@ -145,7 +145,10 @@ def test_maxpool_known_answers(ua, dtype, golden):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(3, 32, 16, 5, 7), (2, 64, 32, 8, 8), (2, 8, 4, 3, 3), (4, 512, 256, 2, 2)])
+@pytest.mark.parametrize("shape", [(3, 32, 16, 5, 7), (2, 64, 32, 8, 8), (2, 8, 4, 3, 3), (4, 512, 256, 2, 2),
+                                   (3, 128, 64, 7, 5), (2, 64, 24, 6, 6),
+                                   # >= 65536 pixels: the streaming kernel (weights in LDS), with a ragged last block
+                                   (67, 64, 32, 32, 31), (70, 128, 64, 31, 31), (66, 64, 24, 32, 32)])
 def test_convt2x2(ua, dtype, shape):
     B, Cin, Cout, H, W = shape
     ops = ua.ops
@@ -172,7 +175,9 @@ def test_convt2x2(ua, dtype, shape):
     dxm = ops.from_nhwc(ops.convt2x2_dgrad(dcat, wb, Cin, Cout, mask=ops.to_nhwc(mask_src.cuda(), dtype), dy_coff=cp), Cin).cpu()
     assert rel(dxm, xr.grad * (mask_src > 0)) < TOL[dtype]
     dW, db = ops.convt2x2_wgrad(xn, dcat, Cin, Cout, dy_coff=cp)
-    assert rel(dW.cpu(), wr.grad) < TOL_W[dtype] and rel(db.cpu(), br.grad) < TOL_W[dtype]
+    # the bias gradient sums B*2H*2W signed values: at 265 K terms the fp32 reference sum itself is only good
+    # to ~1e-5, so it is held to the gradient bar (5e-5) rather than to the operator tolerance
+    assert rel(dW.cpu(), wr.grad) < TOL_W[dtype] and rel(db.cpu(), br.grad) < max(TOL_W[dtype], 5e-5)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -29,6 +29,8 @@ int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
+bool tconv_eligible(const IgemmArgs& a);
+int launch_tconv_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_f32(const WgradArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_bf16(const WgradArgs& a, hipStream_t s, const char** name);
 
@@ -99,6 +101,8 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
     p.units = a.Hi * a.Wi * p.img_tiles * p.n_tiles;
     return dtype == MI_BF16 ? launch_pconv_bf16(p, s, name) : launch_pconv_f32(p, s, name);
   }
+  // transposed convs with many pixels and a weight matrix that fits in LDS: streaming kernel
+  if (dtype == MI_BF16 && tconv_eligible(a)) return launch_tconv_bf16(a, s, name);
   return dtype == MI_BF16 ? launch_igemm_bf16(a, s, name) : launch_igemm_f32(a, s, name);
 }
 
