@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").replace("_GLOBAL__N_1", "")
     m = re.match(r"_ZN2mi\d+([a-z0-9_]+_kernel)I(.*?)EEv", name)
     if m:
         args = m.group(2).replace("DF16b", "bf16,").replace("Li", "").replace("E", ",").replace("Lb", "")

@@ -652,6 +652,83 @@ __global__ __launch_bounds__(256) void head_bwd_small_kernel(const T* __restrict
   for (int i = threadIdx.x; i < COUT * CP + COUT; i += 256)
     part[(int64_t)blockIdx.x * (COUT * CP + COUT) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
+// Head backward for 3..16 output channels on a 32-channel input (the multi-step prediction head):
+// four threads share a pixel, each owning 8 of its input channels, so the dW rows a thread keeps
+// in registers are COUTP x 8 instead of COUTP x 32 and the loads stay 16 bytes wide.  Partials have
+// the layout of the kernel above.  (Measured alternatives that were slower at 128x128x64 images:
+// eight threads per pixel exchanging dpred by lane shuffles, and four pixels in flight per thread;
+// the strided dpred planes, not latency, bound this kernel.)
+template <typename T, int COUTP>
+__global__ __launch_bounds__(256) void head_bwd_mid_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                            const float* __restrict__ w, const float* __restrict__ dpred,
+                                                            T* __restrict__ dx, int dcs, int dco, float* __restrict__ part,
+                                                            int64_t npix, int HW, int Cin, int Cout, int relu_mask) {
+  constexpr int CP = 32;
+  __shared__ float sw[COUTP * CP];
+  __shared__ float red[4][COUTP * CP + COUTP];
+  for (int i = threadIdx.x; i < COUTP * CP; i += 256) {
+    const int co = i / CP, c = i % CP;
+    sw[i] = (co < Cout && c < Cin) ? w[co * Cin + c] : 0.f;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 3;                       // channels 8*cg .. 8*cg+7
+  float acc[COUTP][8], accb[COUTP];
+#pragma unroll
+  for (int co = 0; co < COUTP; ++co) {
+    accb[co] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[co][q] = 0.f;
+  }
+  constexpr int N = Vec16<T>::N;
+  for (int64_t p = blockIdx.x * 64ll + (threadIdx.x >> 2); p < npix; p += (int64_t)gridDim.x * 64) {
+    const uint32_t b = (uint32_t)p / (uint32_t)HW, r = (uint32_t)p - b * (uint32_t)HW;
+    float g[COUTP];
+#pragma unroll
+    for (int co = 0; co < COUTP; ++co) {                // clamped address, then select: all loads in flight
+      const float v = dpred[((int64_t)b * Cout + (co < Cout ? co : 0)) * HW + r];
+      g[co] = co < Cout ? v : 0.f;
+      accb[co] += g[co];
+    }
+    float xv[8], d[8];
+#pragma unroll
+    for (int c = 0; c < 8; c += N) Vec16<T>::load(x + p * xcs + xco + cg * 8 + c, xv + c);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = 0.f;
+#pragma unroll
+    for (int co = 0; co < COUTP; ++co)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        d[q] = fmaf(g[co], sw[co * CP + cg * 8 + q], d[q]);
+        acc[co][q] = fmaf(g[co], xv[q], acc[co][q]);
+      }
+    if (relu_mask) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[q] = xv[q] > 0.f ? d[q] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c += N) Vec16<T>::store(dx + p * dcs + dco + cg * 8 + c, d + c);
+  }
+  // lanes with equal (lane & 3) hold the same channel group: butterfly over the other lane bits
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int co = 0; co < COUTP; ++co) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = acc[co][q];
+#pragma unroll
+      for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane < 4) red[wave][co * CP + cg * 8 + q] = v;
+    }
+    float vb = cg == 0 ? accb[co] : 0.f;                // the four threads of a pixel all saw its dpred
+    vb = wave_sum(vb);
+    if (lane == 0) red[wave][COUTP * CP + co] = vb;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cout * CP + Cout; i += 256) {
+    const int src = i < Cout * CP ? i : COUTP * CP + (i - Cout * CP);
+    part[(int64_t)blockIdx.x * (Cout * CP + Cout) + i] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+  }
+}
 __global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restrict__ part, int nblocks, int Cin, int Cp,
                                                             int Cout, float* __restrict__ dW, float* __restrict__ db,
                                                             float alpha, float beta) {
@@ -699,6 +776,24 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
     }
 #undef HEAD_SMALL
     int rc2 = check_hip(hipGetLastError(), "head_bwd_small");
+    if (rc2) return rc2;
+    const int np2 = Cout * Cp + Cout;
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(np2), dim3(64), 0, s, (const float*)ws, nb, Cin, Cp, Cout, dW, db, alpha, beta);
+    return check_hip(hipGetLastError(), "head_finalize");
+  }
+  if (Cp == 32) {
+    int nb = (int)((npix + 63) / 64);
+    if (nb > kHeadBlocks) nb = kHeadBlocks;
+#define HEAD_MID(TT, COP)                                                                                          \
+    hipLaunchKernelGGL((head_bwd_mid_kernel<TT, COP>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred,   \
+                       (TT*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, Cout, relu_mask)
+    if (dtype == MI_BF16) {
+      if (Cout <= 4) HEAD_MID(__bf16, 4); else if (Cout <= 8) HEAD_MID(__bf16, 8); else if (Cout <= 12) HEAD_MID(__bf16, 12); else HEAD_MID(__bf16, 16);
+    } else {
+      if (Cout <= 4) HEAD_MID(float, 4); else if (Cout <= 8) HEAD_MID(float, 8); else if (Cout <= 12) HEAD_MID(float, 12); else HEAD_MID(float, 16);
+    }
+#undef HEAD_MID
+    int rc2 = check_hip(hipGetLastError(), "head_bwd_mid");
     if (rc2) return rc2;
     const int np2 = Cout * Cp + Cout;
     hipLaunchKernelGGL(head_finalize_kernel, dim3(np2), dim3(64), 0, s, (const float*)ws, nb, Cin, Cp, Cout, dW, db, alpha, beta);
