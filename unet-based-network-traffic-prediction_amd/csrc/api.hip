@@ -213,8 +213,10 @@ struct WgradLayout {
   bool halo;
   int R, G, bands, pitch, HR, tiles_per_split, slabs;
   bool posmajor;   // tiny images: reduce over the in-bounds pixels of each tap only
+  int blocks;      // halo-tile kernel: workgroups per pixel split
 };
-WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
+// `co_blocks`: (n-block, c-block) workgroups per split of a second layer sharing the launch (0 = none)
+WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Cout, int dtype, int co_blocks = 0) {
   WgradLayout l{};
   const int Np = pad_ch(Cout), Cp = concat_cp(Cin, split), K = 9 * Cp;
   const int M = B * H * W;
@@ -224,7 +226,8 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
     const int ntiles = M / 256;
     const int nblk = Np % 64 == 0 ? Np / 64 : (Np + 31) / 32;
     const int blocks = nblk * (Cp / 32);                                       // (n-block, c-block) workgroups per split
-    int splits = (256 + blocks - 1) / blocks;                                  // about one workgroup per CU
+    l.blocks = blocks;
+    int splits = (256 + blocks + co_blocks - 1) / (blocks + co_blocks);        // about one workgroup per CU
     if (splits > ntiles) splits = ntiles;
     l.tiles_per_split = (ntiles + splits - 1) / splits;
     l.splits = (ntiles + l.tiles_per_split - 1) / l.tiles_per_split;
@@ -248,6 +251,48 @@ WgradLayout convt_wgrad_layout(int B, int H, int W, int Cin, int Cout, int dtype
   l.sum_bytes = (size_t)l.splits * K * sizeof(float);
   return l;
 }
+static int hwgrad_args(HwgradArgs& h, const WgradLayout& l, const void* x, int xcs, int xco, const void* dy, int ycs,
+                       int yco, void* ws, int B, int H, int W, int Cin, int split, int Cout) {
+  h.dy = dy; h.dy_cs = ycs; h.dy_co = yco; h.Na = pad_ch(Cout);
+  h.x = x; h.x_cs = xcs; h.x_co = xco; h.Cb = concat_cp(Cin, split);
+  h.W = W; h.R = l.R; h.G = l.G; h.pitch = l.pitch; h.HR = l.HR; h.bands = l.bands;
+  h.ntiles = B * H * W / 256; h.tiles_per_split = l.tiles_per_split; h.splits = l.splits;
+  h.part = (float*)ws;
+  h.rowsum = (float*)((char*)ws + l.part_bytes);
+  h.zero = zero_page();
+  MI_REQUIRE(h.zero != nullptr, "conv3x3_wgrad: cannot resolve the zero page on this device");
+  MI_REQUIRE(x && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && xcs % 16 == 0 && xco % 16 == 0 &&
+                 ycs % 16 == 0 && yco % 16 == 0, "conv3x3_wgrad: operands must be 16-byte aligned views");
+  return MI_OK;
+}
+// Two 3x3 layers over the same pixels (the two convs of a block) in one weight-gradient launch;
+// false when either layer does not take the halo-tile kernel or their channel-block widths differ.
+bool conv3x3_wgrad_pairable(int B, int H, int W, int Cin0, int split0, int Cout0, int Cin1, int split1, int Cout1, int dtype) {
+  const WgradLayout l0 = conv3x3_wgrad_layout(B, H, W, Cin0, split0, Cout0, dtype);
+  const WgradLayout l1 = conv3x3_wgrad_layout(B, H, W, Cin1, split1, Cout1, dtype);
+  return l0.halo && l1.halo && (pad_ch(Cout0) % 64 == 0) == (pad_ch(Cout1) % 64 == 0);
+}
+int run_conv3x3_wgrad_pair(const Conv3WgradCall& c0, const Conv3WgradCall& c1, float alpha, float beta, int B, int H, int W,
+                           int dtype, hipStream_t s, const char** name, FinJobs* defer) {
+  MI_REQUIRE(defer != nullptr, "conv3x3_wgrad_pair: needs a combine-job table");
+  const WgradLayout s0 = conv3x3_wgrad_layout(B, H, W, c0.Cin, c0.split, c0.Cout, dtype);
+  const WgradLayout s1 = conv3x3_wgrad_layout(B, H, W, c1.Cin, c1.split, c1.Cout, dtype);
+  MI_REQUIRE(s0.halo && s1.halo, "conv3x3_wgrad_pair: layers must take the halo-tile kernel");
+  const WgradLayout l0 = conv3x3_wgrad_layout(B, H, W, c0.Cin, c0.split, c0.Cout, dtype, s1.blocks);
+  const WgradLayout l1 = conv3x3_wgrad_layout(B, H, W, c1.Cin, c1.split, c1.Cout, dtype, s0.blocks);
+  if (c0.ws_bytes < l0.part_bytes + l0.sum_bytes || c1.ws_bytes < l1.part_bytes + l1.sum_bytes)
+    return fail(MI_ESIZE, "conv3x3_wgrad_pair: workspace too small");
+  HwgradArgs h[2]{};
+  int rc = hwgrad_args(h[0], l0, c0.x, c0.xcs, c0.xco, c0.dy, c0.ycs, c0.yco, c0.ws, B, H, W, c0.Cin, c0.split, c0.Cout);
+  if (rc) return rc;
+  rc = hwgrad_args(h[1], l1, c1.x, c1.xcs, c1.xco, c1.dy, c1.ycs, c1.yco, c1.ws, B, H, W, c1.Cin, c1.split, c1.Cout);
+  if (rc) return rc;
+  rc = launch_hwgrad_bf16(h, 2, s, name);
+  if (rc) return rc;
+  rc = fin_jobs_add_conv3(*defer, h[0].part, h[0].rowsum, l0.slabs, h[0].Na, h[0].Cb, c0.Cout, c0.Cin, c0.split, c0.dW, c0.db, alpha, beta);
+  if (rc) return rc;
+  return fin_jobs_add_conv3(*defer, h[1].part, h[1].rowsum, l1.slabs, h[1].Na, h[1].Cb, c1.Cout, c1.Cin, c1.split, c1.dW, c1.db, alpha, beta);
+}
 int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
                       float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W, int Cin, int split,
                       int Cout, int dtype, hipStream_t s, const char** name, FinJobs* defer) {
@@ -255,17 +300,9 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
   if (ws_bytes < l.part_bytes + l.sum_bytes) return fail(MI_ESIZE, "conv3x3_wgrad: workspace too small");
   if (l.halo) {
     HwgradArgs h{};
-    h.dy = dy; h.dy_cs = ycs; h.dy_co = yco; h.Na = pad_ch(Cout);
-    h.x = x; h.x_cs = xcs; h.x_co = xco; h.Cb = concat_cp(Cin, split);
-    h.W = W; h.R = l.R; h.G = l.G; h.pitch = l.pitch; h.HR = l.HR; h.bands = l.bands;
-    h.ntiles = B * H * W / 256; h.tiles_per_split = l.tiles_per_split; h.splits = l.splits;
-    h.part = (float*)ws;
-    h.rowsum = (float*)((char*)ws + l.part_bytes);
-    h.zero = zero_page();
-    MI_REQUIRE(h.zero != nullptr, "conv3x3_wgrad: cannot resolve the zero page on this device");
-    MI_REQUIRE(x && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && xcs % 16 == 0 && xco % 16 == 0 &&
-                   ycs % 16 == 0 && yco % 16 == 0, "conv3x3_wgrad: operands must be 16-byte aligned views");
-    int rc = launch_hwgrad_bf16(h, s, name);
+    int rc = hwgrad_args(h, l, x, xcs, xco, dy, ycs, yco, ws, B, H, W, Cin, split, Cout);
+    if (rc) return rc;
+    rc = launch_hwgrad_bf16(&h, 1, s, name);
     if (rc) return rc;
     FinJobs one{};
     FinJobs& J = defer ? *defer : one;

@@ -116,7 +116,16 @@ struct HwgradArgs {
 };
 bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR);
 int hwgrad_slabs_per_split(int Na);
-int launch_hwgrad_bf16(const HwgradArgs& a, hipStream_t s, const char** name);
+// One layer's operands for a paired weight-gradient launch (api.hip: run_conv3x3_wgrad_pair).
+struct Conv3WgradCall {
+  const void* x; int xcs, xco;
+  const void* dy; int ycs, yco;
+  float* dW; float* db;
+  void* ws; size_t ws_bytes;
+  int Cin, split, Cout;
+};
+struct HwgradBatch { HwgradArgs layer[2]; int n, wgs0; };   // wgs0 = workgroups of layer 0
+int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const char** name);
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
 int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
 // Fixed-order combination of the partials into dW / db, several layers per launch (the table is

@@ -41,8 +41,9 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
   return u.v;
 }
 
+// Work of workgroup (bx, by, bz) = (n-block, c-block, pixel split) of one layer.
 template <int NB>
-__global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
+__device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, const int by, const int bz, char* smem) {
   typedef __bf16 T;
   constexpr int COMBOS = (NB / 32) * 2;        // (n-pair, c-tile) accumulator blocks
   constexpr int PG = 8 / COMBOS;               // waves sharing a block split the pixels PG ways
@@ -53,10 +54,8 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
   constexpr int DY_CPR = NB / 8;               // 16-byte chunks per dy row
   constexpr int DY_IT = 256 * DY_CPR / 512;
   constexpr int X_IT = kHwMaxHalo * 4 / 512;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int n0 = blockIdx.x * NB, c0 = blockIdx.y * 32, z = blockIdx.z;
+  const int n0 = bx * NB, c0 = by * 32, z = bz;
   const T* __restrict__ pdy = (const T*)a.dy;
   const T* __restrict__ px = (const T*)a.x;
   const int grp_rows = (a.R + 2) * a.pitch;
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) { acc[tp][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[tp][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   accr[0] = accr[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool do_rows = a.rowsum != nullptr && blockIdx.y == 0 && ct == 0;
+  const bool do_rows = a.rowsum != nullptr && by == 0 && ct == 0;
   const bf16x8_t ones = ones_frag(T());
 
   auto compute = [&](int buf) {
@@ -266,6 +265,24 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradArgs a) {
   }
 }
 
+// One launch serves up to two layers (the two convs of a U-Net block see the same pixels): the
+// workgroups of both share the CUs, so each layer needs only its share of pixel splits to fill
+// the chip and writes that many fewer partial slabs.  Workgroup ids run over layer 0 then layer 1,
+// n-block fastest.
+template <int NB>
+__global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradBatch p) {
+  constexpr int STAGE = 256 * NB * 2 + kHwMaxHalo * 64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  int id = blockIdx.x;
+  const int li = (p.n > 1 && id >= p.wgs0) ? 1 : 0;
+  if (li) id -= p.wgs0;
+  const HwgradArgs& a = p.layer[li];
+  const int gx = (a.Na + NB - 1) / NB, gy = a.Cb / 32;
+  const int bz = id / (gx * gy), rem = id - bz * (gx * gy);
+  const int by = rem / gx, bx = rem - by * gx;
+  hwgrad_body<NB>(a, bx, by, bz, smem);
+}
+
 // Tiling with a 16-row-aligned halo pitch; false when the kernel does not apply.
 bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR) {
   if (!hconv_tiling(H, W, R, G, bands)) return false;
@@ -275,18 +292,27 @@ bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR
 }
 int hwgrad_slabs_per_split(int) { return 1; }
 
-int launch_hwgrad_bf16(const HwgradArgs& a_in, hipStream_t s, const char** name) {
-  HwgradArgs a = a_in;
-  a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
-  a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
-  if (a.Na % 64 == 0) {
-    dim3 grid(a.Na / 64, a.Cb / 32, a.splits);
+static int hwgrad_wgs(const HwgradArgs& a, int NB) { return (a.Na + NB - 1) / NB * (a.Cb / 32) * a.splits; }
+int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const char** name) {
+  MI_REQUIRE(n == 1 || n == 2, "hwgrad: one or two layers per launch");
+  HwgradBatch p{};
+  p.n = n;
+  const int NB = layers[0].Na % 64 == 0 ? 64 : 32;
+  for (int i = 0; i < n; ++i) {
+    HwgradArgs a = layers[i];
+    MI_REQUIRE((a.Na % 64 == 0 ? 64 : 32) == NB, "hwgrad: layers of one launch must share the channel-block width");
+    a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
+    a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
+    p.layer[i] = a;
+  }
+  p.wgs0 = hwgrad_wgs(p.layer[0], NB);
+  const int total = p.wgs0 + (n > 1 ? hwgrad_wgs(p.layer[1], NB) : 0);
+  if (NB == 64) {
     if (name) *name = "hwgrad_64x32x9";
-    hipLaunchKernelGGL((hwgrad_kernel<64>), grid, dim3(512), 0, s, a);
+    hipLaunchKernelGGL((hwgrad_kernel<64>), dim3(total), dim3(512), 0, s, p);
   } else {
-    dim3 grid((a.Na + 31) / 32, a.Cb / 32, a.splits);
     if (name) *name = "hwgrad_32x32x9";
-    hipLaunchKernelGGL((hwgrad_kernel<32>), grid, dim3(512), 0, s, a);
+    hipLaunchKernelGGL((hwgrad_kernel<32>), dim3(total), dim3(512), 0, s, p);
   }
   return check_hip(hipGetLastError(), "hwgrad launch");
 }

@@ -34,6 +34,9 @@ int run_conv3x3_wgrad(const void*, int, int, const void*, int, int, float*, floa
                       int, int, int, int, int, hipStream_t, const char**, FinJobs*);
 int run_convt_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
                     int, int, int, int, hipStream_t, const char**, FinJobs*);
+bool conv3x3_wgrad_pairable(int, int, int, int, int, int, int, int, int, int);
+int run_conv3x3_wgrad_pair(const Conv3WgradCall&, const Conv3WgradCall&, float, float, int, int, int, int, hipStream_t,
+                           const char**, FinJobs*);
 
 enum LayerKind { K_CONV3 = 0, K_CONVT = 1, K_CONV1 = 2 };
 struct Layer {
@@ -133,6 +136,8 @@ struct Run {   // per-call context
   int rc;
   // weight-gradient launches of the current backward segment, issued together by flush_wgrads()
   std::vector<std::function<int(hipStream_t)>> deferred;
+  struct WJob { const struct Layer* l; View x, dy; float* grads; float alpha, beta; int B, H, W; std::string label; };
+  std::vector<WJob> wjobs;   // the 3x3 layers among them (two over the same pixels share one launch)
   FinJobs fin{};   // their combine jobs, one launch per segment
   View view(const std::string& name, int coff = 0) const {
     const int id = P->tensor_id(name);
@@ -239,22 +244,44 @@ int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, in
 }
 int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float alpha, float beta, int B, int H, int W,
                   const char* label) {
-  const std::string lab = label;
-  const Layer* lp = &l;
-  Run* rp = &r;
-  r.deferred.push_back([=](hipStream_t ws) -> int {
-    const Layer& l = *lp;
-    Run& r = *rp;
-    const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
-    const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
-    Scope sc(r.P, ws, lab.c_str(), fl, by);
+  r.wjobs.push_back(Run::WJob{&l, x, dy, grads, alpha, beta, B, H, W, label});
+  return MI_OK;
+}
+static Conv3WgradCall wgrad_call(const Run& r, const Run::WJob& j) {
+  const Layer& l = *j.l;
+  return Conv3WgradCall{j.x.p, j.x.cs, j.x.co, j.dy.p, j.dy.cs, j.dy.co, j.grads + l.w_off, j.grads + l.b_off,
+                        r.ws + l.part_off, l.part_bytes, l.cin, l.split, l.cout};
+}
+static int launch_conv_wgrads(Run& r, hipStream_t ws) {
+  auto flops = [](const Run::WJob& j) { return 2.0 * j.B * j.H * j.W * (double)j.l->cout * j.l->cin * 9; };
+  auto bytes = [&](const Run::WJob& j) { return (double)j.B * j.H * j.W * (j.l->cin + j.l->cout) * esz(r.P); };
+  const int dt = r.P->d.dtype;
+  size_t i = 0;
+  while (i < r.wjobs.size()) {
+    const Run::WJob& a = r.wjobs[i];
+    if (i + 1 < r.wjobs.size()) {
+      const Run::WJob& b = r.wjobs[i + 1];
+      if (a.B == b.B && a.H == b.H && a.W == b.W && a.alpha == b.alpha && a.beta == b.beta &&
+          conv3x3_wgrad_pairable(a.B, a.H, a.W, a.l->cin, a.l->split, a.l->cout, b.l->cin, b.l->split, b.l->cout, dt)) {
+        Scope sc(r.P, ws, (a.label + "+" + b.l->prefix).c_str(), flops(a) + flops(b), bytes(a) + bytes(b));
+        const char* k = nullptr;
+        int rc = run_conv3x3_wgrad_pair(wgrad_call(r, a), wgrad_call(r, b), a.alpha, a.beta, a.B, a.H, a.W, dt, ws, &k, &r.fin);
+        sc.kernel(k);
+        if (rc) return rc;
+        i += 2;
+        continue;
+      }
+    }
+    const Layer& l = *a.l;
+    Scope sc(r.P, ws, a.label.c_str(), flops(a), bytes(a));
     const char* k = nullptr;
-    int rc = run_conv3x3_wgrad(x.p, x.cs, x.co, dy.p, dy.cs, dy.co, grads + l.w_off, grads + l.b_off, alpha, beta,
-                               r.ws + l.part_off, l.part_bytes, B, H, W, l.cin, l.split, l.cout, r.P->d.dtype, ws, &k,
-                               &r.fin);
+    int rc = run_conv3x3_wgrad(a.x.p, a.x.cs, a.x.co, a.dy.p, a.dy.cs, a.dy.co, a.grads + l.w_off, a.grads + l.b_off, a.alpha,
+                               a.beta, r.ws + l.part_off, l.part_bytes, a.B, a.H, a.W, l.cin, l.split, l.cout, dt, ws, &k, &r.fin);
     sc.kernel(k);
-    return rc;
-  });
+    if (rc) return rc;
+    ++i;
+  }
+  r.wjobs.clear();
   return MI_OK;
 }
 // Issues the deferred weight-gradient launches of a segment on the side stream behind ONE fork
@@ -262,10 +289,11 @@ int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float a
 // then ONE launch that combines the partials of all of them: every layer has its own partial
 // region, so the sums need not sit between the weight-gradient kernels as dependent launches.
 int flush_wgrads(Run& r, int seg) {
-  if (r.deferred.empty()) return MI_OK;
+  if (r.deferred.empty() && r.wjobs.empty()) return MI_OK;
   hipStream_t ws = fork_side(r);
-  int rc = MI_OK;
   r.fin.n = 0;
+  int rc = launch_conv_wgrads(r, ws);
+  if (rc) { r.wjobs.clear(); r.deferred.clear(); return rc; }
   for (auto& f : r.deferred) {
     rc = f(ws);
     if (rc) break;
