@@ -81,11 +81,18 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
       h.N = a.N; h.bias = a.epi == E_PLAIN ? nullptr : a.bias; h.n_real = a.n_real; h.relu = a.epi == E_BIAS_RELU;
       h.out = a.out; h.out_cs = a.out_cs; h.out_co = a.out_co;
       h.mask = a.mask; h.mask_cs = a.mask_cs; h.mask_co = a.mask_co;
+      if (a.pool != nullptr) {
+        MI_REQUIRE(a.mask == nullptr && (a.Wi == 4 || a.Wi == 8 || a.Wi == 16) && a.Hi % 2 == 0 && R % 2 == 0 &&
+                       a.pool_cs % 16 == 0 && a.pool_co % 16 == 0 && aligned16(a.pool),
+                   "conv3x3_fwd: the pooled output cannot be fused for this shape");
+        h.pool = a.pool; h.pool_cs = a.pool_cs; h.pool_co = a.pool_co;
+      }
       h.W = a.Wi; h.R = R; h.G = G; h.pitch = (a.Wi + 2 + 7) / 8 * 8; h.HR = G * (R + 2) * h.pitch; h.bands = bands;
       h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
       return dtype == MI_BF16 ? launch_hconv_bf16(h, s, name) : launch_hconv_f32(h, s, name);
     }
   }
+  MI_REQUIRE(a.pool == nullptr, "conv3x3_fwd: the pooled output cannot be fused for this shape");
   // other 3x3 stride-1 convolutions on images of at most 16 pixels take the position-major kernel
   // (skips the taps that fall on the padding, splits K inside the workgroup)
   if (a.mode == G_3x3 && a.epi != E_SHUFFLE_BIAS && a.Hi == a.Ho && a.Wi == a.Wo && a.Hi * a.Wi <= kPconvMaxHW &&
@@ -104,6 +111,15 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
   // transposed convs with many pixels and a weight matrix that fits in LDS: streaming kernel
   if (dtype == MI_BF16 && tconv_eligible(a)) return launch_tconv_bf16(a, s, name);
   return dtype == MI_BF16 ? launch_igemm_bf16(a, s, name) : launch_igemm_f32(a, s, name);
+}
+
+bool conv3x3_fwd_fuses_pool(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
+  (void)Cout;
+  const int M = B * H * W, ck = dtype == MI_BF16 ? 32 : 16;
+  int R, G, bands;
+  if (M % 256 != 0 || concat_cp(Cin, split) % ck != 0 || !hconv_tiling(H, W, &R, &G, &bands) || !(G == 1 || B % G == 0))
+    return false;
+  return (W == 4 || W == 8 || W == 16) && H % 2 == 0 && R % 2 == 0;
 }
 
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split) {

@@ -77,6 +77,7 @@ struct IgemmArgs {
   const float* bias; int n_real;         // bias has n_real entries (unpadded parameter)
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;  // optional: out *= (mask > 0)
+  void* pool; int pool_cs, pool_co;        // optional (3x3 forward only): also write the 2x2 max-pool of the output
   int epi;
   int shufC;                             // E_SHUFFLE_BIAS: N = 4*shufC
   int M;
@@ -84,6 +85,8 @@ struct IgemmArgs {
   const void* zero;                      // zero page (filled in by launch_igemm)
 };
 int launch_igemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
+// Whether the 3x3 forward of this shape can write the 2x2 max-pool of its output in the same launch.
+bool conv3x3_fwd_fuses_pool(int B, int H, int W, int Cin, int split, int Cout, int dtype);
 
 // ---------------------------------------------------------------- weight gradient (wgrad.hip)
 // part[z][n][k] = sum_{p in split z} a[p][n] * b[gather(p,tap)][c],  k = tap*Cb + c

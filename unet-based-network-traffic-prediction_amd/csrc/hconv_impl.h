@@ -30,6 +30,7 @@ struct HconvArgs {
   int N; const float* bias; int n_real; int relu;
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;
+  void* pool; int pool_cs, pool_co;     // optional: 2x2 max-pool of the (post-ReLU) output, written as well (W = 4, 8, 16)
   int W, R, G;                          // image width, rows per group, groups per tile (G*R*W = 256)
   int pitch;                            // halo slots per image row: W+2 rounded up to a multiple of 8
   int HR;                               // halo slots per tile = G*(R+2)*pitch
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   const int r16 = lane & 15, ch = lane >> 4;
   int paddr[TM][3];
   int out_off[TM], mask_off[TM];
+  int pool_off[TM];                // element offset of this lane's pooled pixel inside the pooled tile, or -1 (not its writer)
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int pl = (wave * TM + j) * 16 + r16;         // pixel index inside the tile
@@ -211,6 +213,9 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
     }
     out_off[j] = pl * a.out_cs + a.out_co + n0 + 4 * TN * ch;
     mask_off[j] = pl * a.mask_cs + a.mask_co + n0 + 4 * TN * ch;
+    // the lane of the even row and even column of a 2x2 window writes its maximum
+    const int pooled = g * (a.R >> 1) * (a.W >> 1) + (y >> 1) * (a.W >> 1) + (x >> 1);
+    pool_off[j] = ((y | x) & 1) ? -1 : pooled * a.pool_cs + a.pool_co + n0 + 4 * TN * ch;
   }
   int wfrag[TN];                   // this lane's weight-fragment address inside a tap's BN rows, per channel tile
 #pragma unroll
@@ -310,6 +315,42 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
           v[4 * i + q] = (a.relu && !(x > 0.f)) ? 0.f : x;
         }
       store_run(otile + out_off[j], v, CPL);
+    }
+    if (a.pool != nullptr) {
+      // MaxPool2d(2,2) of the tile fused here (models/unet2d.py:68): the window partners are other
+      // lanes of the same wave (column: lane^1; row: the other fragment when W = 16, lane^W when a
+      // fragment holds two or four rows).  max commutes with the rounding to the storage type.
+      T* ptile = (T*)a.pool + (int64_t)tile * (BM / 4) * a.pool_cs;
+      auto val = [&](int i, int j, int q) {
+        const float x = acc[i][j][q] + biasv[4 * i + q];
+        return (a.relu && !(x > 0.f)) ? 0.f : x;
+      };
+      if (a.W == 16) {
+        static_assert(TM == 2, "fragments 0 and 1 of a wave are vertically adjacent rows when W = 16");
+        float m[CPL];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float t = fmaxf(val(i, 0, q), val(i, 1, q));
+            m[4 * i + q] = fmaxf(t, __shfl_xor(t, 1, 64));
+          }
+        if (pool_off[0] >= 0) store_run(ptile + pool_off[0], m, CPL);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          float m[CPL];
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float t = val(i, j, q);
+              t = fmaxf(t, __shfl_xor(t, a.W, 64));
+              m[4 * i + q] = fmaxf(t, __shfl_xor(t, 1, 64));
+            }
+          if (pool_off[j] >= 0) store_run(ptile + pool_off[j], m, CPL);
+        }
+      }
     }
   };
 

@@ -220,13 +220,14 @@ int join_side(Run& r) {
     if (rc__ != MI_OK) return rc__; \
   } while (0)
 
-int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, const char* label) {
+int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, const char* label, const View* pool = nullptr) {
   const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
-  const double by = (double)B * H * W * (l.cin + l.cout) * esz(r.P);
+  const double by = (double)B * H * W * (l.cin + l.cout * (pool ? 1.25 : 1.0)) * esz(r.P);
   Scope sc(r.P, r.s, label, fl, by);
   const char* k = nullptr;
   IgemmArgs a = conv3x3_fwd_args(x.p, x.cs, x.co, r.ws + l.wf_off, r.Bv(l), y.p, y.cs, y.co, B, H, W, l.cin, l.split,
                                  l.cout, 1);
+  if (pool) { a.pool = pool->p; a.pool_cs = pool->cs; a.pool_co = pool->co; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
   return rc;
@@ -683,8 +684,10 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     const Layer& c2 = P->layers[P->layer_id("downs." + s + ".2")];
     View a1 = r.view("a1." + s), cat = r.view("cat." + s), pool = r.view("pool." + s);
     RUN(do_conv_fwd(r, c1, cur, a1, B, P->h[l], P->w[l], c1.prefix.c_str()));
-    RUN(do_conv_fwd(r, c2, a1, cat, B, P->h[l], P->w[l], c2.prefix.c_str()));
-    {
+    // the 2x2 max-pool rides in the epilogue of the level's second conv where the tile geometry allows
+    const bool fused = conv3x3_fwd_fuses_pool(B, P->h[l], P->w[l], c2.cin, c2.split, c2.cout, dt);
+    RUN(do_conv_fwd(r, c2, a1, cat, B, P->h[l], P->w[l], c2.prefix.c_str(), fused ? &pool : nullptr));
+    if (!fused) {
       Scope sc(P, r.s, ("pool." + s).c_str(), 0, (double)B * P->h[l] * P->w[l] * f * 1.25 * esz(P));
       sc.kernel("maxpool2_fwd");
       RUN(launch_maxpool2_fwd(cat.p, cat.cs, 0, pool.p, pool.cs, 0, B, P->h[l], P->w[l], f, dt, r.s));
