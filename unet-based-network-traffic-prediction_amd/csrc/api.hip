@@ -82,7 +82,7 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
       h.out = a.out; h.out_cs = a.out_cs; h.out_co = a.out_co;
       h.mask = a.mask; h.mask_cs = a.mask_cs; h.mask_co = a.mask_co;
       if (a.pool != nullptr) {
-        MI_REQUIRE(a.mask == nullptr && (a.Wi == 4 || a.Wi == 8 || a.Wi == 16) && a.Hi % 2 == 0 && R % 2 == 0 &&
+        MI_REQUIRE(a.mask == nullptr && a.Hi % 2 == 0 && a.Wi % 2 == 0 && R % 2 == 0 &&
                        a.pool_cs % 16 == 0 && a.pool_co % 16 == 0 && aligned16(a.pool),
                    "conv3x3_fwd: the pooled output cannot be fused for this shape");
         h.pool = a.pool; h.pool_cs = a.pool_cs; h.pool_co = a.pool_co;
@@ -119,7 +119,7 @@ bool conv3x3_fwd_fuses_pool(int B, int H, int W, int Cin, int split, int Cout, i
   int R, G, bands;
   if (M % 256 != 0 || concat_cp(Cin, split) % ck != 0 || !hconv_tiling(H, W, &R, &G, &bands) || !(G == 1 || B % G == 0))
     return false;
-  return (W == 4 || W == 8 || W == 16) && H % 2 == 0 && R % 2 == 0;
+  return H % 2 == 0 && W % 2 == 0 && R % 2 == 0;
 }
 
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split) {

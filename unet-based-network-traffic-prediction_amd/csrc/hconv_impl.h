@@ -30,7 +30,7 @@ struct HconvArgs {
   int N; const float* bias; int n_real; int relu;
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;
-  void* pool; int pool_cs, pool_co;     // optional: 2x2 max-pool of the (post-ReLU) output, written as well (W = 4, 8, 16)
+  void* pool; int pool_cs, pool_co;     // optional: 2x2 max-pool of the (post-ReLU) output, written as well
   int W, R, G;                          // image width, rows per group, groups per tile (G*R*W = 256)
   int pitch;                            // halo slots per image row: W+2 rounded up to a multiple of 8
   int HR;                               // halo slots per tile = G*(R+2)*pitch
@@ -202,7 +202,12 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
   int pool_off[TM];                // element offset of this lane's pooled pixel inside the pooled tile, or -1 (not its writer)
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int pl = (wave * TM + j) * 16 + r16;         // pixel index inside the tile
+    // Fragment (16 consecutive pixels of a row) -> (wave, j).  For W >= 16 a wave's two fragments are
+    // the same 16 columns of two vertically adjacent rows (2k, 2k+1), so the fused 2x2 max-pool pairs
+    // rows inside a lane; for narrower images a fragment holds 2 or 4 whole rows itself.
+    const int cpr = a.W >= 16 ? a.W >> 4 : 1;           // fragments per image row
+    const int frag = a.W >= 16 ? (2 * (wave / cpr) + j) * cpr + (wave % cpr) : wave * TM + j;
+    const int pl = frag * 16 + r16;                     // pixel index inside the tile
     const int g = (int)fdiv((uint32_t)pl, a.d_rw), rem = pl - g * (a.R * a.W);
     const int y = (int)fdiv((uint32_t)rem, a.d_w), x = rem - y * a.W;
     const int hrow = g * grp_rows + y * a.pitch + x;   // halo slot of tap (0,0)
@@ -318,15 +323,15 @@ __global__ __launch_bounds__(256 / (TM * 16) * 64) void hconv_kernel(const Hconv
     }
     if (a.pool != nullptr) {
       // MaxPool2d(2,2) of the tile fused here (models/unet2d.py:68): the window partners are other
-      // lanes of the same wave (column: lane^1; row: the other fragment when W = 16, lane^W when a
-      // fragment holds two or four rows).  max commutes with the rounding to the storage type.
+      // lanes of the same wave (column: lane^1; row: the wave's other fragment when W >= 16, lane^W
+      // when a fragment holds two or four rows).  max commutes with the rounding to the storage type.
       T* ptile = (T*)a.pool + (int64_t)tile * (BM / 4) * a.pool_cs;
       auto val = [&](int i, int j, int q) {
         const float x = acc[i][j][q] + biasv[4 * i + q];
         return (a.relu && !(x > 0.f)) ? 0.f : x;
       };
-      if (a.W == 16) {
-        static_assert(TM == 2, "fragments 0 and 1 of a wave are vertically adjacent rows when W = 16");
+      if (a.W >= 16) {
+        static_assert(TM == 2, "fragments 0 and 1 of a wave are vertically adjacent rows when W >= 16");
         float m[CPL];
 #pragma unroll
         for (int i = 0; i < TN; ++i)
