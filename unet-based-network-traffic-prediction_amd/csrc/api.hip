@@ -243,7 +243,8 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
     const int nblk = Np % 64 == 0 ? Np / 64 : (Np + 31) / 32;
     const int blocks = nblk * (Cp / 32);                                       // (n-block, c-block) workgroups per split
     l.blocks = blocks;
-    int splits = (256 + blocks + co_blocks - 1) / (blocks + co_blocks);        // about one workgroup per CU
+    int splits = 256 / (blocks + co_blocks);                                   // one workgroup per CU, never a second round
+    if (splits < 1) splits = 1;
     if (splits > ntiles) splits = ntiles;
     l.tiles_per_split = (ntiles + splits - 1) / splits;
     l.splits = (ntiles + l.tiles_per_split - 1) / l.tiles_per_split;
