@@ -110,6 +110,41 @@ def test_per_layer_outputs_and_gradients(ua, golden, name, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(8, 64, 32), (16, 16, 64), (4, 128, 16), (32, 8, 16), (32, 16, 8), (64, 8, 32), (16, 16, 128)])
+def test_rectangular_images_against_oracle(ua, shape, dtype):
+    """Non-square power-of-two images: tiles that are bands of an image, whole images, or several
+    images (the geometry the fused max-pool indexes by), checked layer by layer against the CPU oracle."""
+    B, H, W = shape
+    bar = BAR[dtype]
+    feats = (8, 16, 32)
+    state = O.init_state_dict(12, 1, feats, seed=3)
+    model = ua.UNet(12, 1, feats, compute_dtype=dtype)
+    model.load_state_dict(state)
+    model = model.to("cuda")
+    X, Y = O.synthetic_batch(B, 12, 1, H, W, seed=4)
+    loss_ref, taps, _, pgrads, dX = O.forward_backward(state, X, Y, None, want_input_grad=True)
+    Xg = X.cuda().requires_grad_(True)
+    pred = model(Xg)
+    loss = ua.MSELoss()(pred, Y.cuda())
+    loss.backward()
+    assert rel(pred.detach().cpu(), taps["out"]) < bar["out"]
+    names = model.last_plan.tensors()
+    checked = 0
+    for k, ref in taps.items():
+        if "act." + k in names:
+            e = rel(model.workspace_tensor("act." + k).cpu(), ref)
+            assert e < bar["out"], (k, e)
+            checked += 1
+            if k.startswith("pool.") and dtype == "fp32":       # max-pool is exact given its input
+                got_in = model.workspace_tensor("act.downs." + k[5:] + ".3")
+                assert torch.equal(model.workspace_tensor("act." + k), torch.nn.functional.max_pool2d(got_in, 2)), k
+    assert checked >= 3 * len(feats) + 2
+    errs = {k: rel(p.grad.cpu(), pgrads[k]) for k, p in model.named_parameters()}
+    assert max(errs.values()) < bar["grad"], sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert rel(Xg.grad.cpu(), dX) < bar["grad"]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["small4", "odd", "cfg1_full", "cfg2_b32"])
 def test_loss_after_n_adam_steps(ua, golden, name, dtype):
     """The loop body of train.py:382-393 (forward, MSE, zero_grad, backward, Adam step) for

@@ -421,7 +421,10 @@ inline bool hconv_tiling(int H, int W, int* R, int* G, int* bands) {
     if (256 % HW != 0) return false;
     *R = H; *G = 256 / HW; *bands = 1;
   }
-  return (*G) * (*R + 2) * ((W + 2 + 7) / 8 * 8) <= kHconvBigHalo;
+  // the wide-halo variant's bank swizzle assumes a halo pitch of 8 slots (a vertical tap shift
+  // flips bit 3 of the slot index): only 4-wide images have it
+  const int pitch = (W + 2 + 7) / 8 * 8, slots = (*G) * (*R + 2) * pitch;
+  return slots <= kHconvMaxHalo || (slots <= kHconvBigHalo && pitch == 8);
 }
 
 template <typename T>
