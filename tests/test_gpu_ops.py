@@ -49,6 +49,28 @@ def gen(*shape, seed=0, scale=1.0, shift=0.0):
                                    # wide images: two 128-pixel rows per halo tile
                                    (2, 32, 64, 4, 128, 0), (1, 64, 32, 6, 128, 32)])
 def test_conv3x3_fwd_dgrad_wgrad(ua, dtype, shape):
+    _check_conv3x3(ua, dtype, shape)
+
+
+def _geometry_sweep():
+    """Every power-of-two image size the tile kernels can see, batch chosen for at least two 256-pixel tiles."""
+    shapes = []
+    for H in (2, 4, 8, 16, 32, 64):
+        for W in (4, 8, 16, 32, 64, 128):
+            if H * W > 4096:
+                continue
+            B = max(2, 512 // (H * W))
+            shapes.append((B, 32, 64, H, W, 0))
+    return shapes
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", _geometry_sweep())
+def test_conv3x3_image_geometries(ua, dtype, shape):
+    _check_conv3x3(ua, dtype, shape)
+
+
+def _check_conv3x3(ua, dtype, shape):
     B, Cin, Cout, H, W, split = shape
     ops = ua.ops
     x = rnd(dtype, gen(B, Cin, H, W, seed=1, shift=0.3))
