@@ -237,6 +237,19 @@ int mi_unet_backward(mi_unet_plan* plan, const float* dpred_nchw, const float* p
                      size_t ws_bytes, float* grads_flat, float alpha, float beta, int seg_lo, int seg_hi,
                      float* dx_nchw, mi_stream s);
 
+/* Bucketed callers (no counterpart in the reference, which is single-device): mi_unet_backward runs
+ * the weight-gradient kernels on a second stream of the plan and, by default, makes the caller's
+ * stream wait for them before it returns.  With defer_join on, a call over a PARTIAL segment range
+ * instead leaves that stream ahead: it has waited for everything the call put on the caller's
+ * stream, so a collective enqueued behind mi_unet_plan_side_stream() sees the finished gradient
+ * range while the next call's dgrad chain starts without a stall.  The call whose range ends at the
+ * last segment joins the two streams as usual.  mi_unet_plan_side_stream returns NULL when the plan
+ * runs on one stream (profiling on, UNET_TM_SERIAL_BACKWARD=1, or no stream found that runs
+ * concurrently with caller_stream): then there is nothing to defer.  The stream is chosen on first
+ * use, which synchronises caller_stream once. */
+int mi_unet_plan_defer_join(mi_unet_plan* plan, int on);
+void* mi_unet_plan_side_stream(mi_unet_plan* plan, mi_stream caller_stream);
+
 /* Per-launch timing: when enabled, forward/backward bracket every kernel launch with
  * HIP events on the launch stream.  mi_unet_profile_read synchronises those events and
  * returns, for launch i, the kernel name, a layer label, algorithmic FLOPs and bytes,

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mi_unet_plan_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "mi_unet_forward": (_i, [_p, _p, _p, _p, _sz, _p, _i, _p]),
     "mi_unet_backward": (_i, [_p, _p, _p, _p, _sz, _p, _f, _f, _i, _i, _p, _p]),
+    "mi_unet_plan_defer_join": (_i, [_p, _i]),
+    "mi_unet_plan_side_stream": (_p, [_p, _p]),
     "mi_unet_profile_enable": (_i, [_p, _i]),
     "mi_unet_profile_count": (_i, [_p]),
     "mi_unet_profile_read": (_i, [_p, _i, C.c_char_p, _i, C.c_char_p, _i, C.POINTER(C.c_double),

@@ -20,7 +20,10 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -92,6 +95,8 @@ struct mi_unet_plan {
   // second stream for the weight-gradient kernels of a backward call (see fork_side)
   hipStream_t side;
   bool side_tried, side_busy;
+  bool side_owned;   // the plan created `side` itself (destroyed with the plan); otherwise it is the process-wide choice
+  bool defer_join;   // partial backward calls leave the side stream un-joined (see mi_unet_plan_defer_join)
   std::vector<hipEvent_t> sync_pool;
   size_t sync_used;
 
@@ -188,14 +193,76 @@ hipEvent_t next_sync_event(mi_unet_plan* P) {
   }
   return P->sync_pool[P->sync_used++];
 }
+// Calibration kernels for the choice of the side stream.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  int it = 0;
+  while (wall_clock64() - t0 < ticks && ++it < (1 << 22)) {}
+}
+__global__ void noop_kernel() {}
+// HIP maps streams onto a few hardware queues, and two streams on one queue run their kernels one
+// after the other (which queue a new stream gets depends on what the process created before: with
+// the collective library initialised first, the plain "next stream" shared the caller's queue and
+// the two-stream backward ran slower than the one-stream one).  So the side stream is CHOSEN: of a
+// handful of new streams, the first on which a trivial kernel finishes while a 50 us spin kernel
+// still occupies the caller's stream.  If none does, backward stays on one stream.
+// The choice is made once per (device, caller stream) and shared by every plan of the process; the
+// rejected candidates are kept (a handful of idle streams) rather than destroyed.
+static std::mutex g_side_mutex;
+static std::map<std::pair<int, hipStream_t>, hipStream_t> g_side_choice;
+static hipStream_t choose_side_stream(hipStream_t main) {
+  constexpr int kCandidates = 8;
+  hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+  hipStream_t chosen = nullptr;
+  int tried = 0;
+  if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess) {
+    for (; tried < kCandidates && !chosen; ++tried) {
+      hipStream_t c = nullptr;
+      if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+      bool ok = hipEventRecord(e0, main) == hipSuccess;
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, main, 5000ll);      // 50 us at the 100 MHz wall clock
+      ok = ok && hipEventRecord(ea, main) == hipSuccess;
+      hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, c);
+      ok = ok && hipEventRecord(eb, c) == hipSuccess;
+      ok = ok && hipEventSynchronize(ea) == hipSuccess && hipEventSynchronize(eb) == hipSuccess;
+      float ta = 0.f, tb = 0.f;
+      ok = ok && hipEventElapsedTime(&ta, e0, ea) == hipSuccess && hipEventElapsedTime(&tb, e0, eb) == hipSuccess;
+      if (ok && tb < 0.5f * ta) chosen = c;
+    }
+  }
+  (void)hipGetLastError();
+  if (e0) (void)hipEventDestroy(e0);
+  if (ea) (void)hipEventDestroy(ea);
+  if (eb) (void)hipEventDestroy(eb);
+  if (getenv("UNET_TM_DEBUG_STREAMS")) fprintf(stderr, "[unet_tm] side stream: %s after %d candidates\n", chosen ? "found" : "none", tried);
+  return chosen;
+}
+static void ensure_side(mi_unet_plan* P, hipStream_t main) {
+  if (P->side_tried) return;
+  P->side_tried = true;
+  const char* env = getenv("UNET_TM_SERIAL_BACKWARD");
+  if (env && env[0] == '1') return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  const auto key = std::make_pair(dev, main);
+  auto it = g_side_choice.find(key);
+  if (it != g_side_choice.end()) { P->side = it->second; return; }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    // first use under a capture: no measurement possible, take a plain new stream for this plan only
+    (void)hipGetLastError();
+    if (hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess) P->side = nullptr;
+    P->side_owned = true;
+    return;
+  }
+  P->side = choose_side_stream(main);
+  g_side_choice[key] = P->side;
+}
 hipStream_t fork_side(Run& r) {
   mi_unet_plan* P = r.P;
   if (P->profile) return r.s;
-  if (!P->side_tried) {
-    P->side_tried = true;
-    const char* env = getenv("UNET_TM_SERIAL_BACKWARD");
-    if (!(env && env[0] == '1') && hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking) != hipSuccess) P->side = nullptr;
-  }
+  ensure_side(P, r.s);
   if (!P->side) return r.s;
   hipEvent_t e = next_sync_event(P);
   if (!e || hipEventRecord(e, r.s) != hipSuccess || hipStreamWaitEvent(P->side, e, 0) != hipSuccess) return r.s;
@@ -402,7 +469,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   P->forward_done = false;
   P->profile = false;
   P->events_used = 0;
-  P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0;
+  P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0; P->defer_join = false; P->side_owned = false;
   P->cap_stream = nullptr; P->graph_mode = -1;
   P->h.resize(L + 1); P->w.resize(L + 1);
   P->h[0] = d.height; P->w[0] = d.width;
@@ -571,7 +638,7 @@ void mi_unet_plan_destroy(mi_unet_plan* plan) {
   if (!plan) return;
   for (hipEvent_t e : plan->event_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : plan->sync_pool) (void)hipEventDestroy(e);
-  if (plan->side) (void)hipStreamDestroy(plan->side);
+  if (plan->side && plan->side_owned) (void)hipStreamDestroy(plan->side);
   for (auto& g : plan->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (plan->cap_stream) (void)hipStreamDestroy(plan->cap_stream);
@@ -921,7 +988,15 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
     }
     RUN(flush_wgrads(r, seg));
   }
-  return (phases & PH_BODY) ? join_side(r) : MI_OK;
+  if (!(phases & PH_BODY)) return MI_OK;
+  if (P->defer_join && seg_hi < (int)P->segs.size() && P->side_busy) {
+    // bucketed caller: the side stream catches up with this call's main-stream work instead of the
+    // main stream waiting for the weight gradients; the caller reduces the finished range on the
+    // side stream and the dgrad chain of the next call starts at once.  The last call joins.
+    fork_side(r);
+    return MI_OK;
+  }
+  return join_side(r);
 }
 }  // namespace
 
@@ -948,6 +1023,17 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
     RUN(backward_phases(P, dpred_nchw, params_flat, ws, grads, alpha, beta, lo, seg_hi, dx_nchw, s, PH_OUT));
   }
   return MI_OK;
+}
+
+int mi_unet_plan_defer_join(mi_unet_plan* P, int on) {
+  MI_REQUIRE(P, "unet_plan_defer_join: null plan");
+  P->defer_join = on != 0;
+  return MI_OK;
+}
+void* mi_unet_plan_side_stream(mi_unet_plan* P, mi_stream main) {
+  if (!P || P->profile) return nullptr;
+  ensure_side(P, (hipStream_t)main);
+  return (void*)P->side;
 }
 
 }  // extern "C"

@@ -287,11 +287,25 @@ class UNet(nn.Module):
                                      dx.data_ptr() if dx is not None else None, stream), "unet_backward")
         else:
             alpha = alpha * dp.grad_prescale
+            # A finished bucket is reduced behind the plan's weight-gradient stream (which has caught up
+            # with this call's work on the current stream) so the next call's dgrad chain does not wait
+            # for the bucket's weight gradients; the last call joins the streams, its bucket goes on the
+            # current stream, and the waits below are issued there.
+            side = L.mi_unet_plan_side_stream(plan.handle, stream)
+            ext = None
+            if side:
+                ext = plan.side_stream if getattr(plan, "side_stream", None) is not None else torch.cuda.ExternalStream(side)
+                plan.side_stream = ext
+            check(L.mi_unet_plan_defer_join(plan.handle, 1 if ext is not None else 0), "unet_plan_defer_join")
             for (seg_lo, seg_hi, lo, hi) in dp.buckets_for(plan):
                 check(L.mi_unet_backward(plan.handle, dpred.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(),
                                          plan.ws_bytes, out.data_ptr(), alpha, beta, seg_lo, seg_hi,
                                          dx.data_ptr() if dx is not None else None, stream), "unet_backward")
-                dp.reduce_async(out[lo:hi])
+                if ext is not None and seg_hi < plan.n_segments:
+                    with torch.cuda.stream(ext):
+                        dp.reduce_async(out[lo:hi])
+                else:
+                    dp.reduce_async(out[lo:hi])
             dp.wait_all()
         if staged:
             out = out.clone()
