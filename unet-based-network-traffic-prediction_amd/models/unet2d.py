@@ -81,6 +81,13 @@ class _Plan:
             pass
 
 
+def _contiguous_strides(shape):
+    st = [1] * len(shape)
+    for i in range(len(shape) - 2, -1, -1):
+        st[i] = st[i + 1] * int(shape[i + 1])
+    return tuple(st)
+
+
 class _UNetFunction(torch.autograd.Function):
     """Autograd node for the whole network: forward = one launch sequence, backward = one
     segmented launch sequence writing a flat gradient buffer."""
@@ -96,7 +103,11 @@ class _UNetFunction(torch.autograd.Function):
     def backward(ctx, dpred):
         model, plan = ctx.model, ctx.plan
         flat_grad, dx = model._backward_impl(plan, dpred, out=None, beta=0.0)
-        grads = tuple(flat_grad[o:o + n].view(shape) for (o, n, shape) in model._flat_layout)
+        spec = model._grad_view_spec
+        if spec is None or len(spec) != len(model._flat_layout):
+            spec = model._grad_view_spec = [(tuple(shape), _contiguous_strides(shape), o) for (o, n, shape) in model._flat_layout]
+        # one as_strided per parameter: half the host time of slice + view (46 tensors every step)
+        grads = tuple(flat_grad.as_strided(shape, strides, o) for (shape, strides, o) in spec)
         return (None, dx if ctx.x_requires_grad else None) + grads
 
 
@@ -141,6 +152,7 @@ class UNet(nn.Module):
         self._last_pred: Optional[torch.Tensor] = None
         self._dp = None               # set by distributed.GradientReducer.attach
         self._grad_stage: Optional[torch.Tensor] = None
+        self._grad_view_spec = None
         self.last_plan: Optional[_Plan] = None
 
     # ------------------------------------------------------------------ parameters
@@ -197,6 +209,7 @@ class UNet(nn.Module):
                 view.copy_(p.data)
                 p.data = view
         self._flat, self._flat_layout = flat, layout
+        self._grad_view_spec = None
         for plan in self._plans.values():
             plan.packed_version = None
         return flat
