@@ -375,6 +375,9 @@ def test_one_rank_rccl_group_runs_the_collective_path():
             opt.step()
         torch.cuda.synchronize()
         assert torch.isfinite(loss).item()
+        # several buckets, reduced behind the plan's second stream without joining the streams in between
+        assert len(m._dp.buckets_for(m.last_plan)) >= 2
+        assert getattr(m.last_plan, "side_stream", None) is not None
     finally:
         dist.destroy_process_group()
 
