@@ -194,6 +194,16 @@ int mi_window_batch(const double* series, int64_t n, const int64_t* targets, int
                     int H_in, int W_in, int H_out, int W_out, int overlap_len, int stride,
                     double scale, double offset, float* x, float* y, mi_stream s);
 
+/* ------------------------------------------------------------------ F4: series reconstruction */
+/* Overlap-average of predicted horizons into one series (visualize_results.py:443-476).  pred / gt are
+ * (B, out_len) float rows; slot[g] (device int32, g < n_slots) is the row of window g or -1.  Window
+ * g's horizon lies at raw positions [g*stride + in_len, + out_len), as the reference places it.  For
+ * every position < total (>= (n_slots-1)*stride + in_len + out_len): count = number of horizons
+ * covering it, pred_mean / gt_mean = their float64 average (0 where count is 0). */
+int mi_series_reconstruct(const float* pred, const float* gt, const int32_t* slot, int64_t n_slots, int B,
+                          int in_len, int out_len, int stride, int64_t total, double* pred_mean,
+                          double* gt_mean, int32_t* count, mi_stream s);
+
 /* ------------------------------------------------------------------ A7: whole-network plan */
 /* The orchestration of UNet.forward (models/unet2d.py:61-102) and of its autograd
  * backward as one launch sequence per call.  A plan is immutable shape metadata. */

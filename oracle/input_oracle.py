@@ -188,3 +188,24 @@ def test_metrics(model, batches) -> Tuple[float, float]:
             mse += (d ** 2).sum().item()
             n += d.numel()
     return mae / n, mse / n
+
+
+# --------------------------------------------------------------------------- series reconstruction
+def reconstruct_series(preds: np.ndarray, gts: np.ndarray, idx: np.ndarray, input_len: int, output_len: int,
+                       stride: int):
+    """Overlap-average of predicted horizons back into one series (visualize_results.py:443-476):
+    window g's horizon is laid at raw positions [g*stride + input_len, + output_len) (the reference
+    places it right after the input window, whatever the overlap), sums and counts are kept per
+    position, and the positions with at least one prediction are returned compressed.
+    Returns (pred_series, gt_series, mask) in float64."""
+    idx = np.asarray(idx)
+    total = int(idx.max()) * stride + input_len + output_len
+    ps, gs = np.zeros(total, dtype=np.float64), np.zeros(total, dtype=np.float64)
+    cnt = np.zeros(total, dtype=np.int32)
+    for i in range(preds.shape[0]):
+        a = int(idx[i]) * stride + input_len
+        ps[a:a + output_len] += preds[i, 0].reshape(-1)
+        gs[a:a + output_len] += gts[i, 0].reshape(-1)
+        cnt[a:a + output_len] += 1
+    mask = cnt > 0
+    return ps[mask] / cnt[mask], gs[mask] / cnt[mask], mask

@@ -172,3 +172,42 @@ def test_fit_from_cfg_with_reference_shuffling(ua, golden, tmp_path):
     res = ua.harness.fit_from_cfg(cfg, sw, log=None)                 # builds the model first, as train.py:495 does
     for (tl, vl), (ptl, pvl) in zip(res["history"], h["printed_losses"]):
         assert abs(tl - ptl) <= 5e-5 * ptl + 1e-6 and abs(vl - pvl) <= 5e-5 * pvl + 1e-6
+
+
+@pytest.mark.parametrize("name", ["ref15x24", "stride5", "dense"])
+def test_series_reconstruction_matches_reference(ua, golden, name):
+    """Overlap-averaged series on the device against what the reference's plotting function computed.
+    Float64 averages of float32 terms; the device sums in window order, the reference in batch order:
+    relative 1e-12."""
+    c = golden("recon_cases")
+    H, W, Ho, Wo, st = (int(v) for v in c[name + ".geometry"])
+    pred, gt = torch.from_numpy(c[name + ".pred"]).cuda(), torch.from_numpy(c[name + ".gt"]).cuda()
+    ps, gs, mask = ua.reconstruct_series(pred, gt, c[name + ".idx"], H * W, Ho * Wo, st)
+    assert ps.dtype == torch.float64 and ps.shape[0] == c[name + ".pred_series"].shape[0] == int(mask.sum().item())
+    np.testing.assert_allclose(ps.cpu().numpy(), c[name + ".pred_series"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(gs.cpu().numpy(), c[name + ".gt_series"], rtol=1e-12, atol=0)
+    _, _, omask = IO.reconstruct_series(c[name + ".pred"], c[name + ".gt"], c[name + ".idx"], H * W, Ho * Wo, st)
+    assert np.array_equal(mask.cpu().numpy(), omask)
+
+
+def test_series_reconstruction_large_and_errors(ua):
+    rng = np.random.RandomState(5)
+    H = W = 32
+    for stride, n_win, n_pick in ((1, 5000, 2048), (7, 3000, 700), (1500, 40, 40)):     # dense overlap ... disjoint horizons
+        idx = rng.permutation(n_win)[:n_pick]
+        pred = torch.rand(n_pick, 1, H, W)
+        gt = torch.rand(n_pick, 1, H, W)
+        ps, gs, mask = ua.reconstruct_series(pred.cuda(), gt.cuda(), idx, H * W, H * W, stride)
+        po, go, mo = IO.reconstruct_series(pred.numpy(), gt.numpy(), idx, H * W, H * W, stride)
+        assert np.array_equal(mask.cpu().numpy(), mo)
+        np.testing.assert_allclose(ps.cpu().numpy(), po, rtol=1e-12)
+        np.testing.assert_allclose(gs.cpu().numpy(), go, rtol=1e-12)
+    p = torch.rand(4, 1, 4, 4).cuda()
+    with pytest.raises(ValueError):
+        ua.reconstruct_series(p, p, [0, 1, 1, 2], 16, 16, 1)           # duplicate window
+    with pytest.raises(ValueError):
+        ua.reconstruct_series(p, p, [0, 1, 2], 16, 16, 1)              # one index per row
+    with pytest.raises(ValueError):
+        ua.reconstruct_series(p, p, [0, 1, 2, 3], 16, 15, 1)           # row length
+    with pytest.raises(RuntimeError):
+        ua.reconstruct_series(p.cpu(), p.cpu(), [0, 1, 2, 3], 16, 16, 1)

@@ -172,3 +172,13 @@ def test_fit_bookkeeping_early_stop_and_checkpoint(tmp_path):
     res3 = unet_amd.harness.fit(m3, torch.optim.SGD(m3.parameters(), lr=0.0), crit, lambda e: [(x, y)], lambda e: [(x, y)], 7,
                                 None, False, 3, 0.42, None)
     assert res3["stopped_at"] == 7 and res3["best_epoch"] == 6 and res3["best_val_loss"] == pytest.approx(0.1)
+
+
+@pytest.mark.parametrize("name", ["ref15x24", "stride5", "dense"])
+def test_series_reconstruction_oracle_reproduces_reference(golden, name):
+    """visualize_results.visualize_test_windows_sec_original: the two series it hands to the scaler."""
+    c = golden("recon_cases")
+    H, W, Ho, Wo, st = (int(v) for v in c[name + ".geometry"])
+    p, g, mask = IO.reconstruct_series(c[name + ".pred"], c[name + ".gt"], c[name + ".idx"], H * W, Ho * Wo, st)
+    assert np.array_equal(p, c[name + ".pred_series"]) and np.array_equal(g, c[name + ".gt_series"])
+    assert mask.sum() == p.shape[0]

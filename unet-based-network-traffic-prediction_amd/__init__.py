@@ -10,11 +10,11 @@ from .models import UNet, build_model_from_cfg, build_unet_from_cfg
 from .loss import MSELoss, mse_loss, eval_sums
 from .optim import FusedAdam
 from .distributed import GradientReducer, broadcast_parameters, init_process_group_from_env, shard_batch
-from .data import SeriesWindows, reference_shuffle, reference_open_loader
+from .data import SeriesWindows, reconstruct_series, reference_shuffle, reference_open_loader
 from . import harness
 from . import ops
 
 __all__ = ["UNet", "build_model_from_cfg", "build_unet_from_cfg", "MSELoss", "mse_loss", "eval_sums", "FusedAdam",
-           "GradientReducer", "broadcast_parameters", "init_process_group_from_env", "shard_batch", "SeriesWindows", "reference_shuffle",
+           "GradientReducer", "broadcast_parameters", "init_process_group_from_env", "shard_batch", "SeriesWindows", "reconstruct_series", "reference_shuffle",
            "reference_open_loader", "harness", "ops", "lib",
            "LIB_PATH", "HipLibraryError"]

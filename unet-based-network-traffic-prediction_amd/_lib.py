@@ -57,6 +57,7 @@ SIGNATURES = {
     "mi_series_minmax": (_i, [_p, _i64, _p, _p, _sz, _p]),
     "mi_window_count": (_i64, [_i64, _i, _i, _i, _i, _i, _i]),
     "mi_window_batch": (_i, [_p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _i, C.c_double, C.c_double, _p, _p, _p]),
+    "mi_series_reconstruct": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _i64, _p, _p, _p, _p]),
     "mi_unet_plan_create": (_i, [C.POINTER(UNetDesc), C.POINTER(_p)]),
     "mi_unet_plan_destroy": (None, [_p]),
     "mi_unet_plan_workspace_bytes": (_sz, [_p]),

@@ -96,6 +96,42 @@ __global__ __launch_bounds__(256) void window_batch_kernel(const WindowArgs a) {
   }
 }
 
+
+// Overlap-average of predicted horizons back into one series (visualize_results.py:443-476 of the
+// reference).  One thread per raw position: the windows whose horizon covers it are g in
+// [ceil((pos - in_len - out_len + 1) / stride), floor((pos - in_len) / stride)]; slot[g] is the row
+// of window g in the batch or -1.  Sums run in ascending g in float64 (the reference adds in batch
+// order: equal up to the rounding of a float64 sum of a few float32 terms).
+struct ReconArgs {
+  const float* pred; const float* gt; const int32_t* slot;
+  int64_t n_slots, total;
+  int out_len, in_len, stride;
+  double* pred_mean; double* gt_mean; int32_t* count;
+};
+__global__ __launch_bounds__(256) void reconstruct_kernel(const ReconArgs a) {
+  for (int64_t pos = blockIdx.x * 256ll + threadIdx.x; pos < a.total; pos += (int64_t)gridDim.x * 256) {
+    const int64_t rel = pos - a.in_len;                    // offset from the start of window 0's horizon
+    double ps = 0.0, gs = 0.0;
+    int n = 0;
+    if (rel >= 0) {
+      int64_t g_hi = rel / a.stride;
+      int64_t g_lo = rel - a.out_len + 1 <= 0 ? 0 : (rel - a.out_len + a.stride) / a.stride;   // ceil((rel-out_len+1)/stride)
+      if (g_hi >= a.n_slots) g_hi = a.n_slots - 1;
+      for (int64_t g = g_lo; g <= g_hi; ++g) {
+        const int32_t row = a.slot[g];
+        if (row < 0) continue;
+        const int64_t off = (int64_t)row * a.out_len + (rel - g * a.stride);
+        ps += (double)a.pred[off];
+        gs += (double)a.gt[off];
+        ++n;
+      }
+    }
+    a.count[pos] = n;
+    a.pred_mean[pos] = n ? ps / n : 0.0;
+    a.gt_mean[pos] = n ? gs / n : 0.0;
+  }
+}
+
 }  // namespace
 }  // namespace mi
 
@@ -158,6 +194,19 @@ int mi_window_batch(const double* series, int64_t n, const int64_t* targets, int
   if (vec) hipLaunchKernelGGL(window_batch_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)s, a);
   else hipLaunchKernelGGL(window_batch_kernel<1>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)s, a);
   return check_hip(hipGetLastError(), "window_batch");
+}
+
+int mi_series_reconstruct(const float* pred, const float* gt, const int32_t* slot, int64_t n_slots, int B, int in_len,
+                          int out_len, int stride, int64_t total, double* pred_mean, double* gt_mean, int32_t* count,
+                          mi_stream s) {
+  MI_REQUIRE(pred && gt && slot && pred_mean && gt_mean && count, "series_reconstruct: null pointer");
+  MI_REQUIRE(B > 0 && n_slots > 0 && in_len > 0 && out_len > 0 && stride > 0 && total > 0, "series_reconstruct: bad sizes");
+  MI_REQUIRE(total >= (n_slots - 1) * stride + in_len + out_len, "series_reconstruct: output shorter than the last horizon");
+  ReconArgs a{pred, gt, slot, n_slots, total, out_len, in_len, stride, pred_mean, gt_mean, count};
+  int64_t nb = (total + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(reconstruct_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)s, a);
+  return check_hip(hipGetLastError(), "series_reconstruct");
 }
 
 }  // extern "C"

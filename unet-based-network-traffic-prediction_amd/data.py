@@ -154,3 +154,38 @@ class SeriesWindows:
     def inverse_transform(self, t: torch.Tensor) -> torch.Tensor:
         """MinMaxScaler.inverse_transform (used by test.py:75-76): (x - offset) / scale."""
         return (t.double() - self.offset) / self.scale
+
+
+def reconstruct_series(pred: torch.Tensor, gt: torch.Tensor, idx, input_len: int, output_len: int, stride: int):
+    """Overlap-average of predicted horizons into one series, as visualize_results.py:443-476 does on
+    the host: ``pred`` / ``gt`` are (N, 1, H_out, W_out) device tensors of the windows ``idx`` (original
+    window indices, distinct).  Returns (pred_series, gt_series, mask): float64 device tensors holding
+    the positions covered by at least one horizon (the reference's compressed series) and the boolean
+    mask of those positions over the raw index space."""
+    ids = np.asarray(idx.cpu().numpy() if torch.is_tensor(idx) else idx, dtype=np.int64).reshape(-1)
+    N = int(pred.shape[0])
+    if ids.shape[0] != N or gt.shape[0] != N or N == 0:
+        raise ValueError("reconstruct_series: one window index per prediction row is required")
+    if ids.min() < 0 or np.unique(ids).shape[0] != N:
+        raise ValueError("reconstruct_series: window indices must be distinct and non-negative")
+    if int(np.prod(pred.shape[1:])) != output_len or tuple(gt.shape) != tuple(pred.shape):
+        raise ValueError("reconstruct_series: rows must hold output_len values")
+    if not pred.is_cuda:
+        raise RuntimeError("reconstruct_series needs device tensors: there is no CPU path")
+    dev = pred.device
+    n_slots = int(ids.max()) + 1
+    slot = np.full(n_slots, -1, dtype=np.int32)
+    slot[ids] = np.arange(N, dtype=np.int32)
+    total = int(ids.max()) * stride + input_len + output_len
+    p = pred.detach().float().contiguous()
+    g = gt.detach().float().contiguous()
+    slot_d = torch.from_numpy(slot).to(dev)
+    pm = torch.empty(total, dtype=torch.float64, device=dev)
+    gm = torch.empty(total, dtype=torch.float64, device=dev)
+    cnt = torch.empty(total, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().mi_series_reconstruct(p.data_ptr(), g.data_ptr(), slot_d.data_ptr(), n_slots, N, input_len, output_len,
+                                          stride, total, pm.data_ptr(), gm.data_ptr(), cnt.data_ptr(), _stream()),
+              "series_reconstruct")
+    mask = cnt > 0
+    return pm[mask], gm[mask], mask
