@@ -52,6 +52,14 @@ def test_conv3x3_fwd_dgrad_wgrad(ua, dtype, shape):
     _check_conv3x3(ua, dtype, shape)
 
 
+@pytest.mark.parametrize("shape", [(70, 256, 128, 4, 4, 128), (600, 128, 256, 2, 2, 0), (9, 128, 128, 1, 3, 0),
+                                   (33, 128, 256, 4, 2, 0), (512, 256, 256, 4, 4, 0), (1, 128, 128, 4, 4, 0)])
+def test_conv3x3_tiny_images_wide_channels(ua, shape):
+    """bf16, images of at most 16 pixels with the channel counts of the deepest levels: the per-tap
+    weight-gradient reduction (ragged pixel ranges, one and many splits, concat input, 1-row images)."""
+    _check_conv3x3(ua, torch.bfloat16, shape)
+
+
 def _geometry_sweep():
     """Every power-of-two image size the tile kernels can see, batch chosen for at least two 256-pixel tiles."""
     shapes = []

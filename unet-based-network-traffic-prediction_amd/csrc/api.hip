@@ -331,7 +331,7 @@ int run_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, 
   a.b = x; a.b_cs = xcs; a.b_co = xco; a.Cb = concat_cp(Cin, split);
   a.B = B; a.Hb = H; a.Wb = W; a.Ho = H; a.Wo = W;
   a.taps = 9; a.mode = l.posmajor ? G_3x3P : G_3x3;
-  a.divB = make_fastdiv(B);
+  MI_REQUIRE(!l.posmajor || B * H * W < (1 << 27), "conv3x3_wgrad: pixel count out of range");
   a.part = (float*)ws;
   a.rowsum = (float*)((char*)ws + l.part_bytes);
   a.splits = l.splits; a.pix_per_split = l.pps;

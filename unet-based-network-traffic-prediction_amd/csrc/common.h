@@ -103,7 +103,7 @@ struct WgradArgs {
   float* colsum;                           // [splits][K] or null
   int splits, pix_per_split;
   int M;
-  FastDiv divHW, divW, divB;
+  FastDiv divHW, divW;
   const void* zero;                        // zero page (filled in by launch_wgrad)
 };
 // Halo-tile weight gradient (hwgrad_bf16.hip): 3x3 convs on evenly tiling images, bf16 only.

@@ -12,8 +12,8 @@
 // On images of a few pixels most (pixel, tap) pairs of a 3x3 conv fall on the zero padding
 // (20 of 36 on a 2x2 image).  Mode G_3x3P therefore reduces over a per-tap list instead: a
 // k-tile lies inside one tap (Cb % 64 == 0), and its workgroups walk only the in-bounds
-// positions of that tap, position-major over the batch -- no padding rows are loaded or
-// multiplied.
+// positions of that tap, image by image (neighbouring pixels stay neighbours in memory, so the
+// rows of a stage spread over all memory channels) -- no padding rows are loaded or multiplied.
 // Row sums of a (bias gradient of a conv) and column sums of b (bias gradient of a
 // transposed conv) come from extra MFMAs against an all-ones fragment.
 #pragma once
@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const int64_t zoff_b = ((intptr_t)a.zero - (intptr_t)a.b) / (int64_t)sizeof(T);
   int pbeg = z * a.pix_per_split;
   int pend = min(a.M, pbeg + a.pix_per_split);
-  // G_3x3P: the reduction index e runs over (valid position, image); [pbeg,pend) is a range of e
-  int vy0 = 0, vx0 = 0, nvx = 1;
+  // G_3x3P: the reduction index e runs over (image, valid position); [pbeg,pend) is a range of e
+  int vy0 = 0, vx0 = 0, nvx = 1, nval = 1;
+  uint32_t mul_nv = 0, mul_nx = 0;
   if (MODE == G_3x3P) {
     const int tap = k0 / a.Cb;
     const int ty = tap / 3, ddy = ty - 1, ddx = tap - ty * 3 - 1;
@@ -114,6 +115,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     nvx = a.Wb - (ddx != 0 ? 1 : 0);
     const int nvy = a.Hb - (ddy != 0 ? 1 : 0);
     pend = min(nvy * nvx * a.B, pend);
+    // exact reciprocal multipliers (nval <= 16, e < 2^27, position < 16)
+    nval = max(1, nvy * nvx);
+    nvx = max(1, nvx);
+    mul_nv = 0xFFFFFFFFu / (uint32_t)nval + 1u;
+    mul_nx = 256u / (uint32_t)nvx + 1u;
   }
   const int cch = t % CPR, row0 = t / CPR;
   // a-operand chunk: channels n0 + cch*EPC ..
@@ -144,11 +150,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       int p = pstage + row0 + i * RPP;
       const bool pv = p < pend;
       if (MODE == G_3x3P) {
-        // e -> (position index, image) -> pixel; every listed pixel has its tap neighbour in bounds
+        // e -> (image, position index) -> pixel; every listed pixel has its tap neighbour in bounds
         const uint32_t e = pv ? (uint32_t)p : 0u;
-        const uint32_t pi = fdiv(e, a.divB);
-        const uint32_t n = e - pi * (uint32_t)a.B;
-        const uint32_t iy = pi / (uint32_t)nvx, ix = pi - iy * (uint32_t)nvx;
+        const uint32_t n = nval == 1 ? e : __umulhi(e, mul_nv);   // (the multiplier of 1 does not fit 32 bits)
+        const uint32_t pi = e - n * (uint32_t)nval;
+        const uint32_t iy = (pi * mul_nx) >> 8, ix = pi - iy * (uint32_t)nvx;
         p = (int)(n * (uint32_t)HW + (vy0 + iy) * (uint32_t)a.Wb + vx0 + ix);
       }
       const bool av = pv && a_ok;
