@@ -284,6 +284,62 @@ def test_errors(ua):
         ua.UNet(1, 1, (8, 16, 24)).to("cuda")(torch.zeros(1, 1, 16, 16, device="cuda"))
 
 
+def test_overlapping_forward_passes_keep_their_activations(ua):
+    """What stock autograd gives the reference's module: several forward passes may precede one
+    backward, an evaluation may sit between a forward and its backward, gradients accumulate
+    across backward calls, a retained graph can be walked twice -- and a graph whose activations
+    have been overwritten fails loudly instead of returning wrong gradients."""
+    torch.manual_seed(0)
+    m = ua.UNet(3, 2, features=(8, 16), compute_dtype="fp32").cuda()
+    x1 = torch.randn(4, 3, 16, 16, device="cuda")
+    x2 = torch.randn(4, 3, 16, 16, device="cuda")
+    state = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ((O.unet_forward(state, x1.cpu()) ** 2).mean() + (O.unet_forward(state, x2.cpu()) ** 2).mean()).backward()
+    ref = [state[k].grad for k, _ in m.named_parameters()]
+
+    def run(mode):
+        for p in m.parameters():
+            p.grad = None
+        if mode == "one_graph":
+            ((m(x1) ** 2).mean() + (m(x2) ** 2).mean()).backward()
+        elif mode == "accumulate":
+            (m(x1) ** 2).mean().backward()
+            (m(x2) ** 2).mean().backward()
+        elif mode == "zero_in_place":
+            (m(x1) ** 2).mean().backward()
+            for p in m.parameters():
+                p.grad.zero_()
+            (m(x1) ** 2).mean().backward()
+            (m(x2) ** 2).mean().backward()
+        elif mode == "eval_between":
+            loss = (m(x1) ** 2).mean()
+            with torch.no_grad():
+                m(x2)
+            loss.backward()
+            (m(x2) ** 2).mean().backward()
+        elif mode == "retained":
+            loss = (m(x1) ** 2).mean() + (m(x2) ** 2).mean()
+            loss.backward(retain_graph=True)
+            for p in m.parameters():
+                p.grad = None
+            loss.backward()
+        return [p.grad.cpu() for p in m.parameters()]
+
+    for mode in ("one_graph", "accumulate", "zero_in_place", "eval_between", "retained"):
+        for g, r in zip(run(mode), ref):
+            assert rel(g, r) < 5e-5, mode
+    # the standard loop keeps to one workspace: the plan is free again once backward has run
+    n_plans = sum(len(v) for v in m._plans.values())
+    for _ in range(3):
+        (m(x1) ** 2).mean().backward()
+    assert sum(len(v) for v in m._plans.values()) == n_plans
+    loss = (m(x1) ** 2).mean()
+    loss.backward(retain_graph=True)
+    (m(x2) ** 2).mean().backward()            # reuses the released workspace
+    with pytest.raises(RuntimeError, match="activations of this forward pass are gone"):
+        loss.backward()
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_full_size_properties(ua, dtype):
     """Size-independent properties at the benchmark's own size (12ch 32x32, batch 512):

@@ -59,6 +59,10 @@ class _Plan:
             self.segments.append((lo.value, hi.value))
         self.packed_version = None   # parameter version the packed weights correspond to
         self.packed_train = False
+        # A plan's workspace holds the activations of ONE forward pass.  `generation` counts the
+        # passes run on it; `leased` is the generation whose backward is still to come (None = free).
+        self.generation = 0
+        self.leased: Optional[int] = None
 
     def tensors(self) -> Dict[str, dict]:
         """Named activation / gradient views inside the workspace (for parity checks)."""
@@ -81,6 +85,31 @@ class _Plan:
             pass
 
 
+class _Lease:
+    """Keeps a plan's activations reserved for the autograd node of one forward pass: released
+    when its backward has run, or when the node dies without one."""
+
+    __slots__ = ("plan", "generation")
+
+    def __init__(self, plan: _Plan):
+        plan.generation += 1
+        plan.leased = plan.generation
+        self.plan, self.generation = plan, plan.generation
+
+    def intact(self) -> bool:
+        return self.plan.generation == self.generation
+
+    def release(self):
+        if self.plan.leased == self.generation:
+            self.plan.leased = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 def _contiguous_strides(shape):
     st = [1] * len(shape)
     for i in range(len(shape) - 2, -1, -1):
@@ -97,12 +126,17 @@ class _UNetFunction(torch.autograd.Function):
         ctx.model = model
         ctx.x_requires_grad = bool(ctx.needs_input_grad[1])
         ctx.plan = model._forward_impl(x, train=True, need_input_grad=ctx.x_requires_grad)
+        ctx.lease = _Lease(ctx.plan)
         return model._last_pred
 
     @staticmethod
     def backward(ctx, dpred):
         model, plan = ctx.model, ctx.plan
+        if not ctx.lease.intact():
+            raise RuntimeError("UNet: the activations of this forward pass are gone (its backward already ran and "
+                               "a later forward pass reused the workspace); run forward again before backward")
         flat_grad, dx = model._backward_impl(plan, dpred, out=None, beta=0.0)
+        ctx.lease.release()
         spec = model._grad_view_spec
         if spec is None or len(spec) != len(model._flat_layout):
             spec = model._grad_view_spec = [(tuple(shape), _contiguous_strides(shape), o) for (o, n, shape) in model._flat_layout]
@@ -146,7 +180,7 @@ class UNet(nn.Module):
                                           nn.Conv2d(f, f, 3, padding=1), nn.ReLU(inplace=True)))
         self.final_conv = nn.Conv2d(self.features[0], self.out_channels, kernel_size=1)
 
-        self._plans: Dict[Tuple, _Plan] = {}
+        self._plans: Dict[Tuple, List[_Plan]] = {}
         self._flat: Optional[torch.Tensor] = None
         self._flat_layout: List[Tuple[int, int, torch.Size]] = []
         self._last_pred: Optional[torch.Tensor] = None
@@ -210,8 +244,9 @@ class UNet(nn.Module):
                 p.data = view
         self._flat, self._flat_layout = flat, layout
         self._grad_view_spec = None
-        for plan in self._plans.values():
-            plan.packed_version = None
+        for plans in self._plans.values():
+            for plan in plans:
+                plan.packed_version = None
         return flat
 
     def flat_parameters(self) -> torch.Tensor:
@@ -224,20 +259,26 @@ class UNet(nn.Module):
     def mark_parameters_changed(self):
         """Tell the module its parameters were updated through raw pointers (the fused
         optimiser does this) so packed weights are refreshed on the next forward."""
-        for plan in self._plans.values():
-            plan.packed_version = None
+        for plans in self._plans.values():
+            for plan in plans:
+                plan.packed_version = None
 
     # ------------------------------------------------------------------ plans
     def _get_plan(self, x: torch.Tensor, need_input_grad: bool) -> _Plan:
         B, Cc, H, W = x.shape
         key = (B, H, W, x.device.index, bool(need_input_grad), self.compute_dtype)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = _Plan(self, B, H, W, x.device, need_input_grad)
-            flat_elems = lib().mi_unet_plan_flat_elems(plan.handle)
-            if flat_elems != self._flat.numel():
-                raise RuntimeError("internal error: flat parameter layout disagrees with the plan")
-            self._plans[key] = plan
+        # Normally one plan per shape; a forward pass that arrives while an earlier one still
+        # awaits its backward (two passes in one graph, gradient checkpoints, an evaluation between
+        # forward and backward) gets a plan -- and a workspace -- of its own.
+        plans = self._plans.setdefault(key, [])
+        for plan in plans:
+            if plan.leased is None:
+                return plan
+        plan = _Plan(self, B, H, W, x.device, need_input_grad)
+        flat_elems = lib().mi_unet_plan_flat_elems(plan.handle)
+        if flat_elems != self._flat.numel():
+            raise RuntimeError("internal error: flat parameter layout disagrees with the plan")
+        plans.append(plan)
         return plan
 
     # ------------------------------------------------------------------ forward / backward
@@ -331,7 +372,8 @@ class UNet(nn.Module):
             self._check_input(x)
             self._ensure_flat(x.device)      # before autograd records the parameter tensors
             return _UNetFunction.apply(self, x, *self._construction_order())
-        self._forward_impl(x, train=False)
+        plan = self._forward_impl(x, train=False)
+        plan.generation += 1      # whatever an earlier pass left in this workspace is overwritten
         return self._last_pred
 
     # ------------------------------------------------------------------ introspection (tests, debugging)
