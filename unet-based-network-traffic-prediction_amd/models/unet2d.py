@@ -63,6 +63,7 @@ class _Plan:
         # passes run on it; `leased` is the generation whose backward is still to come (None = free).
         self.generation = 0
         self.leased: Optional[int] = None
+        self.graph_mode = _graph_mode()
 
     def tensors(self) -> Dict[str, dict]:
         """Named activation / gradient views inside the workspace (for parity checks)."""
@@ -83,6 +84,11 @@ class _Plan:
                 lib().mi_unet_plan_destroy(self.handle)
         except Exception:
             pass
+
+
+def _graph_mode() -> bool:
+    env = os.environ.get("UNET_TM_GRAPH", "")
+    return env[:1] == "1"        # the library reads the variable the same way, once per plan
 
 
 class _Lease:
@@ -321,14 +327,17 @@ class UNet(nn.Module):
         dpred = dpred.contiguous()
         if dpred.dtype != torch.float32:
             dpred = dpred.float()
-        # Gradients are produced in a buffer that lives as long as the module: its address is part
-        # of the key of the library's captured launch graphs, so it must not change from step to
-        # step.  Callers get a copy (autograd may keep or accumulate into what it is handed).
-        staged = out is None
+        # Autograd may keep, or accumulate into, what it is handed: every pass gets a flat buffer of
+        # its own (the caching allocator hands the previous step's back).  Only with captured launch
+        # graphs (UNET_TM_GRAPH=1) are gradients produced in a buffer that lives as long as the
+        # module and copied out, because its address is part of the key of the captured graphs.
+        staged = out is None and plan.graph_mode
         if staged:
             if self._grad_stage is None or self._grad_stage.shape != flat.shape or self._grad_stage.device != flat.device:
                 self._grad_stage = torch.zeros_like(flat)
             out = self._grad_stage
+        elif out is None:
+            out = torch.empty_like(flat)
         dx = None
         if plan.need_input_grad:
             dx = torch.empty((plan.B, self.in_channels, plan.H, plan.W), device=flat.device, dtype=torch.float32)
