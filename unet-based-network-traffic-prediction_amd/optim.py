@@ -37,6 +37,44 @@ class FusedAdam(torch.optim.Optimizer):
         st = t.untyped_storage()
         return torch.empty(0, dtype=torch.float32, device=t.device).set_(st, 0, (st.nbytes() // 4,))
 
+    def _step_cached(self, gi, group) -> bool:
+        """The usual step: same parameter tensors at the same addresses as last time, every gradient
+        an fp32 view at its parameter's offset inside one flat gradient buffer.  Confirms exactly
+        that (one pointer per tensor, ~20 us of host time instead of ~150 for the full analysis)
+        and launches; returns False to send anything else down the general path."""
+        st = self._flat_state.get(gi)
+        layout = st.get("layout") if st else None
+        if layout is None:
+            return False
+        ids, params, pstart, offsets, flat_p = layout
+        gp = group["params"]
+        if len(gp) != len(ids) or params[0].data_ptr() != pstart:
+            st.pop("layout", None)
+            return False
+        for p, i in zip(gp, ids):
+            if id(p) != i:
+                st.pop("layout", None)
+                return False
+        g0 = params[0].grad
+        if g0 is None:
+            return False
+        gstart = g0.data_ptr()
+        f32 = torch.float32
+        for p, off in zip(params, offsets):
+            g = p.grad
+            if g is None or g.dtype is not f32 or g.data_ptr() != gstart + off or p.data_ptr() != pstart + off:
+                return False
+        n = flat_p.numel()
+        flat_g = self._storage_as_flat(g0)
+        go = (gstart - flat_g.data_ptr()) // 4
+        if go + n > flat_g.numel():
+            return False
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        ops.adam_step(flat_p, flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2, group["eps"], st["step"],
+                      self.grad_scale)
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -44,6 +82,8 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
+            if self._step_cached(gi, group):
+                continue
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
@@ -67,6 +107,9 @@ class FusedAdam(torch.optim.Optimizer):
                     st["v"] = torch.zeros(n, device=flat_p.device, dtype=torch.float32)
                 ops.adam_step(flat_p[po:po + n], flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2,
                               group["eps"], st["step"], self.grad_scale)
+                # remember the layout: later steps only confirm that nothing moved (see _step_cached)
+                st["layout"] = (tuple(id(p) for p in group["params"]), params, pspan[0],
+                                [p.data_ptr() - pspan[0] for p in params], flat_p[po:po + n])
             else:
                 for p in params:
                     ps = self.state[p]
