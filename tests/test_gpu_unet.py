@@ -145,6 +145,38 @@ def test_rectangular_images_against_oracle(ua, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("arch", [
+    # (in, out, features, B, H, W): depths 1..6, widths that are not multiples of 16, one-image batches,
+    # sizes that are odd at some level (both bilinear resizes), many output channels.  (The one-level
+    # net gets 48 images: with 3 its 4x4 bottleneck has 48 pixels and a single bf16-flipped ReLU moves
+    # a gradient tensor by a quarter of its norm.)
+    (1, 1, (8,), 48, 8, 8), (3, 2, (6, 12), 1, 12, 20), (12, 1, (16, 32, 64, 128, 256), 2, 32, 32),
+    (5, 7, (4, 8, 16, 32, 64, 128), 2, 64, 64), (2, 16, (24, 48), 5, 10, 6), (12, 12, (32, 64), 1, 17, 23),
+    (7, 3, (20, 40, 80), 2, 36, 28)])
+def test_architecture_variants_against_oracle(ua, arch, dtype):
+    """The constructor's whole argument space (models/unet2d.py:9-15), not only the benched widths:
+    prediction, every parameter gradient and the input gradient against the CPU oracle."""
+    cin, cout, feats, B, H, W = arch
+    bar = BAR[dtype]
+    state = O.init_state_dict(cin, cout, feats, seed=5)
+    model = ua.UNet(cin, cout, feats, compute_dtype=dtype)
+    model.load_state_dict(state)
+    model = model.to("cuda")
+    X, Y = O.synthetic_batch(B, cin, cout, H, W, seed=6)
+    loss_ref, taps, _, pgrads, dX = O.forward_backward(state, X, Y, None, want_input_grad=True)
+    Xg = X.cuda().requires_grad_(True)
+    pred = model(Xg)
+    assert tuple(pred.shape) == tuple(taps["out"].shape)
+    loss = ua.MSELoss()(pred, Y.cuda())
+    loss.backward()
+    assert rel(pred.detach().cpu(), taps["out"]) < bar["out"]
+    assert abs(loss.item() - loss_ref.item()) <= bar["out"] * abs(loss_ref.item())
+    errs = {k: rel(p.grad.cpu(), pgrads[k]) for k, p in model.named_parameters()}
+    assert max(errs.values()) < bar["grad"], sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert rel(Xg.grad.cpu(), dX) < bar["grad"]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["small4", "odd", "cfg1_full", "cfg2_b32"])
 def test_loss_after_n_adam_steps(ua, golden, name, dtype):
     """The loop body of train.py:382-393 (forward, MSE, zero_grad, backward, Adam step) for
