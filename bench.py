@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--layers-out", default="", help="write per-launch records of the last instrumented step here")
     ap.add_argument("--bucket-mb", type=float, default=8.0, help="gradient all-reduce bucket size (MiB), N > 1 only")
     ap.add_argument("--stock-optim", action="store_true", help="torch.optim.Adam + nn.MSELoss instead of the fused ones")
+    ap.add_argument("--fused-step", action="store_true",
+                    help="UNet.train_step (the same kernels as direct calls, no autograd bookkeeping) instead of the five-line loop body")
     ap.add_argument("--input-pipeline", action="store_true",
                     help="gather every step's batch from a device-resident series (SeriesWindows) inside the timed region")
     args = ap.parse_args()
@@ -160,7 +162,9 @@ def main():
             lo = cursor[0] % 64 * batch
             cursor[0] += 1
             sw.batch(ids[lo:lo + batch], out=(X, Y))
-        if train:
+        if train and args.fused_step:
+            loss_acc.add_(model.train_step(X, Y, opt))
+        elif train:
             pred = model(X)
             loss = crit(pred, Y)
             opt.zero_grad()

@@ -316,6 +316,40 @@ def test_errors(ua):
         ua.UNet(1, 1, (8, 16, 24)).to("cuda")(torch.zeros(1, 1, 16, 16, device="cuda"))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("stock_optim", [False, True])
+def test_train_step_equals_the_loop_body_bit_for_bit(ua, dtype, stock_optim):
+    """UNet.train_step (direct library calls) against forward / MSELoss / zero_grad / backward / step
+    through autograd: same losses and same parameters after six steps, with either optimizer; mixing
+    the two forms in one run works too."""
+    feats = (8, 16, 32)
+    batches = [tuple(t.cuda() for t in O.synthetic_batch(6, 12, 1, 16, 16, seed=s)) for s in range(6)]
+
+    def run(mode):
+        torch.manual_seed(0)
+        m = ua.UNet(12, 1, feats, compute_dtype=dtype).cuda()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3) if stock_optim else ua.FusedAdam(m.parameters(), lr=1e-3, model=m)
+        crit = ua.MSELoss()
+        losses = []
+        for i, (X, Y) in enumerate(batches):
+            if mode == "fused" or (mode == "mixed" and i % 2 == 0):
+                losses.append(m.train_step(X, Y, opt))
+            else:
+                loss = crit(m(X), Y)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach())
+        return torch.stack(losses).cpu(), [p.detach().cpu().clone() for p in m.parameters()]
+
+    l_ref, p_ref = run("loop")
+    for mode in ("fused", "mixed"):
+        l, p = run(mode)
+        assert torch.equal(l, l_ref), mode
+        for a, b in zip(p, p_ref):
+            assert torch.equal(a, b), mode
+
+
 def test_overlapping_forward_passes_keep_their_activations(ua):
     """What stock autograd gives the reference's module: several forward passes may precede one
     backward, an evaluation may sit between a forward and its backward, gradients accumulate
