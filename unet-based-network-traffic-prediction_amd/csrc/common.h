@@ -165,6 +165,7 @@ constexpr int kMaxPackJobs = 32;
 struct PackJob {
   const float* w; void* wf; void* wb;    // wf / wb may be null (that image is not produced)
   int convt, Cout, Cin, split, Np, Cp, Kp, Kp2;
+  int vec;                               // 3x3 layers: packed through LDS with 16-byte accesses (see pack_conv3x3_unit_vec)
   int chunk_end;                         // running count of 1024-element chunks up to and including this job
   uint32_t mKp, mCp, mKp2, mNp;          // fast-division multipliers of Kp, Cp, Kp2, Np (shift 31 + s*)
   uint8_t sKp, sCp, sKp2, sNp;
