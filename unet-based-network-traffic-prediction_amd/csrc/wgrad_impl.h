@@ -211,10 +211,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       const auto a1 = read_frag_tr(At, ks, 2 * wr + 1, lane, T());
       const auto b0 = read_frag_tr(Bt, ks, 2 * wc, lane, T());
       const auto b1 = read_frag_tr(Bt, ks, 2 * wc + 1, lane, T());
-      acc[0][0] = mma_px(a0, b0, acc[0][0]);
-      acc[0][1] = mma_px(a0, b1, acc[0][1]);
-      acc[1][0] = mma_px(a1, b0, acc[1][0]);
-      acc[1][1] = mma_px(a1, b1, acc[1][1]);
+      // the b fragment goes in as the row operand: a lane then holds four CONSECUTIVE k of one n,
+      // and the partials leave as 16-byte stores
+      acc[0][0] = mma_px(b0, a0, acc[0][0]);
+      acc[0][1] = mma_px(b1, a0, acc[0][1]);
+      acc[1][0] = mma_px(b0, a1, acc[1][0]);
+      acc[1][1] = mma_px(b1, a1, acc[1][1]);
       if (do_rows) {
         accr[0] = mma_px(a0, ones, accr[0]);
         accr[1] = mma_px(a1, ones, accr[1]);
@@ -240,19 +242,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
   }
 
-  // D layout: row (= n) = 4*(lane>>4) + j, col (= k) = lane & 15.
+  // D layout of the products: row (= k) = 4*(lane>>4) + q, col (= n) = lane & 15; of the row/column
+  // sums: row = 4*(lane>>4) + q, col = lane & 15 with every column (row) equal.
+  // (K and Na are multiples of 16: a 16 x 16 fragment is inside the matrix or outside it as a whole)
   const int rq = 4 * (lane >> 4), cq = lane & 15;
   float* part = a.part + (int64_t)z * a.Na * K;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int k = k0 + (2 * wc + j) * 16 + cq;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + (2 * wr + i) * 16 + rq + q;
-        if (n < a.Na && k < K) part[(int64_t)n * K + k] = acc[i][j][q];
-      }
+      const int k = k0 + (2 * wc + j) * 16 + rq;
+      const int n = n0 + (2 * wr + i) * 16 + cq;
+      if (n < a.Na && k < K) *(f32x4_t*)(part + (int64_t)n * K + k) = acc[i][j];
     }
   if (do_rows && cq == 0) {
 #pragma unroll
