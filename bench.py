@@ -21,6 +21,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,6 +38,49 @@ WORKLOADS = {
     "cfg5_infer64": (12, 1, (32, 64, 128, 256), 64, 64, 256, False),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X
+
+
+def synthetic_batch(batch, cin, cout, h, w, seed=1):
+    """Synthetic traffic matrices in [0,1) (the reference MinMax-scales its data, dataset.py:326-327):
+    X then Y drawn from one seeded CPU generator."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(batch, cin, h, w, generator=g), torch.rand(batch, cout, h, w, generator=g)
+
+
+def conv_flops_per_sample(cin, cout, feats, h, w):
+    """(forward, train) dense FLOPs per sample of UNet.forward (models/unet2d.py:61-102) on sizes that halve
+    exactly: 2*Cout*Hout*Wout*Cin*kh*kw per conv with padding taps counted, 2*Hin*Win*Cin*Cout*4 per
+    transposed conv; train = forward + weight gradients + input gradients of every layer but the first."""
+    fwd, first, ch = 0, None, cin
+    dims = [(h >> l, w >> l) for l in range(len(feats) + 1)]
+    for l, f in enumerate(feats):                                   # encoder: ch -> f, f -> f at level l
+        lh, lw = dims[l]
+        fl = 2 * lh * lw * 9 * (ch * f + f * f)
+        first = 2 * lh * lw * 9 * ch * f if first is None else first
+        fwd, ch = fwd + fl, f
+    bh, bw = dims[len(feats)]
+    fwd += 2 * bh * bw * 9 * (ch * 2 * ch + 2 * ch * 2 * ch)        # bottleneck
+    for l in reversed(range(len(feats))):                          # decoder: convT 2f -> f, conv 2f -> f, f -> f
+        f, (lh, lw) = feats[l], dims[l]
+        fwd += 2 * (lh // 2) * (lw // 2) * 2 * f * f * 4 + 2 * lh * lw * 9 * (2 * f * f + f * f)
+    fwd += 2 * h * w * feats[0] * cout                              # 1x1 head
+    return fwd, 3 * fwd - first
+
+
+def self_launch(args, argv, device_count=None, run=subprocess.run):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start N fresh worker processes
+    through torch.distributed.run (one per GPU, RCCL rendezvous on 127.0.0.1) BEFORE this process touches
+    a GPU, relay their output (rank 0 prints the JSON line) and return their exit status."""
+    n = device_count() if device_count is not None else torch.cuda.device_count()   # counting does not initialise the GPU
+    if n < args.gpus:
+        print(f"bench: --gpus {args.gpus} needs {args.gpus} GPUs, this machine shows {n}", file=sys.stderr)
+        return 3
+    port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return run(cmd, env=env).returncode
 
 
 def read_profile(model):
@@ -94,7 +138,7 @@ def cpu_baseline(cin, cout, feats, H, W, batch, budget_s=12.0):
                       f"after 1 warm-up step; {dt / n * 1e3:.1f} ms/step"}
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -111,10 +155,13 @@ def main():
                     help="UNet.train_step (the same kernels as direct calls, no autograd bookkeeping) instead of the five-line loop body")
     ap.add_argument("--input-pipeline", action="store_true",
                     help="gather every step's batch from a device-resident series (SeriesWindows) inside the timed region")
-    args = ap.parse_args()
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (N > 1 only)")
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:] if argv is None else argv))
 
     import unet_amd
-    from oracle import unet_oracle as O
     import torch.distributed as dist
 
     rank, world, local = unet_amd.init_process_group_from_env()
@@ -131,7 +178,7 @@ def main():
     torch.manual_seed(0)
     model = unet_amd.UNet(cin, cout, feats, compute_dtype=args.dtype).to(dev)
     # every rank draws the global batch from the same seed and keeps its own rows
-    Xg, Yg = O.synthetic_batch(batch * world, cin, cout, H, W)
+    Xg, Yg = synthetic_batch(batch * world, cin, cout, H, W)
     X = unet_amd.shard_batch(Xg, rank, world).to(dev)
     Y = unet_amd.shard_batch(Yg, rank, world).to(dev)
     del Xg, Yg
@@ -146,7 +193,8 @@ def main():
         pipe = (sw, sw.to_device_ids(rng.randint(cin - 1, sw.num_windows, size=batch * 64)), [0])
 
     force_dp = os.environ.get("UNET_TM_FORCE_DP") == "1"      # one-rank rehearsal of the RCCL path
-    reducer = unet_amd.GradientReducer(bucket_bytes=int(args.bucket_mb * (1 << 20)), force=force_dp).attach(model) if (world > 1 or force_dp) else None
+    reducer = unet_amd.GradientReducer(bucket_bytes=int(args.bucket_mb * (1 << 20)), force=force_dp,
+                                       mode=args.collective).attach(model) if (world > 1 or force_dp) else None
     if world > 1 or force_dp:
         model.flat_parameters()
         unet_amd.broadcast_parameters(model)
@@ -221,7 +269,7 @@ def main():
     fence()
 
     if rank == 0:
-        fwd_fl, train_fl = O.conv_flops_per_sample(cin, cout, feats, H, W)
+        fwd_fl, train_fl = conv_flops_per_sample(cin, cout, feats, H, W)
         flops_per_sample = train_fl if train else fwd_fl
         roof = None
         if per_kernel:
@@ -254,6 +302,9 @@ def main():
                        "step": "fwd+MSE+zero_grad+bwd+Adam" if train else "fwd (no_grad)",
                        "optimizer": "torch.optim.Adam" if args.stock_optim else "FusedAdam (HIP)",
                        "parallelism": f"dp{world}"},
+            "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "dist_backend": dist.get_backend() if dist.is_initialized() else None,
+            "collective": (reducer.mode if reducer is not None else None),
             "conv_mfma_frac_whole_step": round(flops_per_sample * value / world / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
             "gpu_kernel_ms_per_step": round(gpu_ms, 4),
             "roofline": roof,

@@ -5,9 +5,15 @@
  * Every entry point takes raw device pointers, plain ints and a hipStream_t (passed
  * as void*).  The caller owns all memory: outputs and workspaces are caller-allocated,
  * nothing is retained after a call returns, nothing is freed by the library.  Work is
- * enqueued on the given stream; no entry point synchronises.  The return value is 0 on
- * success, a negative MI_E* code for an argument error, or a positive hipError_t.
- * mi_last_error() returns a thread-local description of the last failure.
+ * enqueued on the given stream and no entry point waits for the GPU, with ONE exception:
+ * mi_unet_plan_prepare() (or, if it was never called, the first mi_unet_backward /
+ * mi_unet_plan_side_stream of a process on a given device and caller stream) picks the
+ * second stream the weight-gradient kernels run on by timing two trivial kernels, which
+ * waits for the caller's stream once.  That choice -- one stream per (device, caller
+ * stream), kept for the life of the process -- is the library's only process-wide state.
+ * The return value is 0 on success, a negative MI_E* code for an argument error, or a
+ * positive hipError_t.  mi_last_error() returns a thread-local description of the last
+ * failure.
  *
  * "Reference" below is VoVanVi/Unet-based-Network-Traffic-Prediction; each entry point
  * names the reference call site whose arithmetic it replaces.
@@ -256,9 +262,15 @@ int mi_unet_backward(mi_unet_plan* plan, const float* dpred_nchw, const float* p
  * last segment joins the two streams as usual.  mi_unet_plan_side_stream returns NULL when the plan
  * runs on one stream (profiling on, UNET_TM_SERIAL_BACKWARD=1, or no stream found that runs
  * concurrently with caller_stream): then there is nothing to defer.  The stream is chosen on first
- * use, which synchronises caller_stream once. */
+ * use, which synchronises caller_stream once; mi_unet_plan_prepare makes that first use explicit
+ * (call it once after creating a plan, outside any latency-critical or captured region).
+ * mi_unet_plan_last_call_deferred: 1 when the last mi_unet_backward call on the plan returned with the
+ * side stream ordered BEHIND everything it enqueued (reduce the finished range behind the side stream),
+ * 0 when it joined the streams (the range is complete in caller_stream's order: reduce there). */
+int mi_unet_plan_prepare(mi_unet_plan* plan, mi_stream caller_stream);
 int mi_unet_plan_defer_join(mi_unet_plan* plan, int on);
 void* mi_unet_plan_side_stream(mi_unet_plan* plan, mi_stream caller_stream);
+int mi_unet_plan_last_call_deferred(const mi_unet_plan* plan);
 
 /* Per-launch timing: when enabled, forward/backward bracket every kernel launch with
  * HIP events on the launch stream.  mi_unet_profile_read synchronises those events and

@@ -53,11 +53,21 @@ def test_conv3x3_fwd_dgrad_wgrad(ua, dtype, shape):
 
 
 @pytest.mark.parametrize("shape", [(70, 256, 128, 4, 4, 128), (600, 128, 256, 2, 2, 0), (9, 128, 128, 1, 3, 0),
-                                   (33, 128, 256, 4, 2, 0), (512, 256, 256, 4, 4, 0), (1, 128, 128, 4, 4, 0)])
+                                   (33, 128, 256, 4, 2, 0), (512, 256, 256, 4, 4, 0), (1, 128, 128, 4, 4, 0),
+                                   # the 5-level network's bottleneck (models/unet2d.py:37-42 with features[-1]=512:
+                                   # 512 -> 1024 and 1024 -> 1024, K = 9216) and its first decoder conv (concat 512+512)
+                                   (8, 512, 1024, 4, 4, 0), (8, 1024, 1024, 4, 4, 0), (6, 1024, 512, 8, 8, 512),
+                                   (40, 1024, 1024, 2, 2, 0)])
 def test_conv3x3_tiny_images_wide_channels(ua, shape):
     """bf16, images of at most 16 pixels with the channel counts of the deepest levels: the per-tap
     weight-gradient reduction (ragged pixel ranges, one and many splits, concat input, 1-row images)."""
     _check_conv3x3(ua, torch.bfloat16, shape)
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 1024, 4, 4, 0), (4, 1024, 1024, 4, 4, 0), (2, 1024, 512, 8, 8, 512)])
+def test_conv3x3_1024_channels_fp32(ua, shape):
+    """The same 1024-channel layers through the exact-fp32 kernels."""
+    _check_conv3x3(ua, torch.float32, shape)
 
 
 def _geometry_sweep():
@@ -177,6 +187,8 @@ def test_maxpool_known_answers(ua, dtype, golden):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(3, 32, 16, 5, 7), (2, 64, 32, 8, 8), (2, 8, 4, 3, 3), (4, 512, 256, 2, 2),
                                    (3, 128, 64, 7, 5), (2, 64, 24, 6, 6),
+                                   # the 5-level network's first transposed conv (models/unet2d.py:46-48, 1024 -> 512)
+                                   (2, 1024, 512, 4, 4), (64, 1024, 512, 4, 4),
                                    # >= 65536 pixels: the streaming kernel (weights in LDS), with a ragged last block
                                    (67, 64, 32, 32, 31), (70, 128, 64, 31, 31), (66, 64, 24, 32, 32)])
 def test_convt2x2(ua, dtype, shape):

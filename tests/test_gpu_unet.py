@@ -177,7 +177,7 @@ def test_architecture_variants_against_oracle(ua, arch, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", ["small4", "odd", "cfg1_full", "cfg2_b32"])
+@pytest.mark.parametrize("name", ["small4", "odd", "cfg1_full", "cfg2_b32", "cfg4_b2"])
 def test_loss_after_n_adam_steps(ua, golden, name, dtype):
     """The loop body of train.py:382-393 (forward, MSE, zero_grad, backward, Adam step) for
     20 steps on one fixed batch; the loss curve must track the reference's."""
@@ -238,7 +238,7 @@ def test_unchanged_reference_loop_with_stock_optimizer_and_loss(ua, golden):
     assert np.max(np.abs(np.asarray(losses) - ref) / np.abs(ref)) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["cfg1_full", "cfg2_b32"])
+@pytest.mark.parametrize("name", ["cfg1_full", "cfg2_b32", "cfg4_b2"])
 def test_full_width_samples_and_norms(ua, golden, name):
     g = golden(name)
     cin, cout, feats, osz = meta(g)
@@ -269,6 +269,45 @@ def test_full_width_samples_and_norms(ua, golden, name):
             assert abs(t.double().norm().item() - float(g[k])) <= 1e-5 * float(g[k]), k
             idx = torch.from_numpy(g["actidx." + k[8:]])
             assert rel(t.flatten()[idx], torch.from_numpy(g["actval." + k[8:]])) < 1e-4, k
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_inference_sweep_64x64_against_oracle(ua, dtype):
+    """The inference configuration (test.py:24-47 / :33-38: model.eval(), torch.no_grad(), pred = model(X)):
+    default widths, 12 channels, 64x64 matrices.  Batches 1, 8 and 256 against the CPU oracle's forward
+    pass; batch 8192 (activation tensors beyond 2^31 bytes, so the 64-bit index paths run) through a
+    size-independent property: a batch made of 32 copies of the 256 matrices predicts, row for row,
+    what the 256 alone predict (to rounding only -- the library may pick other kernels at that size)."""
+    bar = BAR[dtype]["out"]
+    state = O.init_state_dict(12, 1, (32, 64, 128, 256), seed=0)
+    model = ua.UNet(12, 1, (32, 64, 128, 256), compute_dtype=dtype)
+    model.load_state_dict(state)
+    model = model.to("cuda").eval()
+    X, _ = O.synthetic_batch(256, 12, 1, 64, 64, seed=7)
+    ref = O.unet_forward(state, X)
+    Xd = X.cuda()
+    with torch.no_grad():
+        p256 = model(Xd).clone()
+        for b in (1, 8):
+            pb = model(Xd[:b])
+            assert tuple(pb.shape) == (b, 1, 64, 64)
+            assert rel(pb.cpu(), ref[:b]) < bar, b
+            for i in range(b):                      # every row on its own, not only the batch's norm
+                assert rel(pb[i].cpu(), ref[i]) < 2 * bar, (b, i)
+        assert rel(p256.cpu(), ref) < bar
+        worst = max(rel(p256[i].cpu(), ref[i]) for i in range(256))
+        assert worst < 2 * bar, worst
+        big = model(Xd.repeat(32, 1, 1, 1))
+        assert tuple(big.shape) == (8192, 1, 64, 64)
+        tol = 1e-6 if dtype == "fp32" else bar
+        for r in (0, 1, 15, 16, 31):
+            assert rel(big[r * 256:(r + 1) * 256], p256) < tol, r
+        assert torch.isfinite(big).all()
+        sums, n = ua.eval_sums(big, torch.zeros_like(big))      # test.py:39-43 at that size
+        assert n == 8192 * 64 * 64
+        assert abs(sums[1].item() - 32 * p256.double().pow(2).sum().item()) <= 1e-4 * sums[1].item()
+    del big, model
+    torch.cuda.empty_cache()
 
 
 def test_state_dict_interchange_and_eval(ua):
@@ -348,6 +387,54 @@ def test_train_step_equals_the_loop_body_bit_for_bit(ua, dtype, stock_optim):
         assert torch.equal(l, l_ref), mode
         for a, b in zip(p, p_ref):
             assert torch.equal(a, b), mode
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_adam_alone_refreshes_packed_weights_and_checkpoints(ua, dtype):
+    """``FusedAdam(model.parameters(), lr=...)`` -- the drop-in for train.py:497, with no reference to the
+    module -- writes the parameters through raw pointers; the module must still notice (packed MFMA
+    weight images refreshed every step), so the run equals, bit for bit, one whose optimizer was also
+    handed the module, and tracks stock torch.optim.Adam.  The optimizer's state_dict has torch.optim.Adam's
+    format and a run resumed from it continues bit for bit."""
+    feats = (8, 16, 32)
+    batches = [tuple(t.cuda() for t in O.synthetic_batch(6, 12, 1, 16, 16, seed=s)) for s in range(8)]
+    crit = ua.MSELoss()
+
+    def run(make_opt, resume_at=None):
+        torch.manual_seed(0)
+        m = ua.UNet(12, 1, feats, compute_dtype=dtype).cuda()
+        opt = make_opt(m)
+        losses = []
+        for i, (X, Y) in enumerate(batches):
+            if resume_at is not None and i == resume_at:
+                sd = opt.state_dict()
+                p0 = next(iter(sd["state"].values()))
+                assert set(p0) >= {"step", "exp_avg", "exp_avg_sq"} and float(p0["step"]) == resume_at
+                stock = torch.optim.Adam(m.parameters(), lr=1e-3)
+                stock.load_state_dict(sd)                    # interchangeable with the stock optimizer's format
+                opt = make_opt(m)
+                opt.load_state_dict(stock.state_dict())
+            loss = crit(m(X), Y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        with torch.no_grad():
+            final = m(batches[0][0]).clone()
+        return torch.stack(losses).cpu(), [p.detach().cpu().clone() for p in m.parameters()], final.cpu()
+
+    with_model = run(lambda m: ua.FusedAdam(m.parameters(), lr=1e-3, model=m))
+    alone = run(lambda m: ua.FusedAdam(m.parameters(), lr=1e-3))
+    resumed = run(lambda m: ua.FusedAdam(m.parameters(), lr=1e-3), resume_at=4)
+    stock = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3))
+    for other in (alone, resumed):
+        assert torch.equal(other[0], with_model[0])
+        assert torch.equal(other[2], with_model[2])
+        for a, b in zip(other[1], with_model[1]):
+            assert torch.equal(a, b)
+    assert with_model[0][0] != with_model[0][-1]
+    tol = 1e-5 if dtype == "fp32" else 2e-3
+    assert ((alone[0] - stock[0]).abs() / stock[0].abs()).max().item() < tol
 
 
 def test_overlapping_forward_passes_keep_their_activations(ua):
@@ -464,6 +551,47 @@ def test_bucketed_backward_matches_single_call():
     assert len(red.calls) > 1 and sum(red.calls) >= sum(p.numel() for p in m.parameters())
     for a, p in zip(g0, m.parameters()):
         assert torch.equal(a, p.grad)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("feats,cout,hw", [((8, 16, 32, 64), 1, (32, 32)), ((8, 16), 3, (17, 23))])
+def test_data_parallel_prescale_reaches_every_gradient(dtype, feats, cout, hw):
+    """Data-parallel runs fold 1/world into the backward pass (alpha of every weight-gradient combine)
+    instead of scaling the flat buffer afterwards: with a prescale of 1/8 EVERY parameter gradient --
+    3x3 convs, transposed convs, the 1x1 head, all biases -- must be one eighth of the unscaled one,
+    while the input gradient (not a parameter gradient, never reduced) stays unscaled."""
+    import unet_amd
+
+    class Recorder(unet_amd.GradientReducer):
+        def reduce_async(self, t):
+            pass
+
+        def wait_all(self):
+            pass
+
+    torch.manual_seed(0)
+    m = unet_amd.UNet(12, cout, feats, compute_dtype=dtype).cuda()
+    X, Y = O.synthetic_batch(8, 12, cout, *hw)
+    X, Y = X.cuda().requires_grad_(True), Y.cuda()
+    crit = unet_amd.MSELoss()
+    crit(m(X), Y).backward()
+    g0 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    dx0 = X.grad.clone()
+    for bucket_bytes in (1, 64 << 10, 1 << 30):          # every segment its own bucket / a few / one
+        red = Recorder(bucket_bytes=bucket_bytes)
+        red.force = True
+        red.grad_prescale = 0.125
+        red.attach(m)
+        for p in m.parameters():
+            p.grad = None
+        X.grad = None
+        crit(m(X), Y).backward()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            assert g0[k].abs().max().item() > 0, k
+            assert rel(p.grad, 0.125 * g0[k]) < 1e-6, (k, bucket_bytes)    # a power of two: exact up to rounding
+        assert torch.equal(X.grad, dx0)
+    m._dp = None
 
 
 def test_one_rank_rccl_group_runs_the_collective_path():

@@ -73,6 +73,8 @@ SIGNATURES = {
     "mi_unet_backward": (_i, [_p, _p, _p, _p, _sz, _p, _f, _f, _i, _i, _p, _p]),
     "mi_unet_plan_defer_join": (_i, [_p, _i]),
     "mi_unet_plan_side_stream": (_p, [_p, _p]),
+    "mi_unet_plan_last_call_deferred": (_i, [_p]),
+    "mi_unet_plan_prepare": (_i, [_p, _p]),
     "mi_unet_profile_enable": (_i, [_p, _i]),
     "mi_unet_profile_count": (_i, [_p]),
     "mi_unet_profile_read": (_i, [_p, _i, C.c_char_p, _i, C.c_char_p, _i, C.POINTER(C.c_double),

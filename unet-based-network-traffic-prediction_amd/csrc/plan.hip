@@ -97,6 +97,7 @@ struct mi_unet_plan {
   bool side_tried, side_busy;
   bool side_owned;   // the plan created `side` itself (destroyed with the plan); otherwise it is the process-wide choice
   bool defer_join;   // partial backward calls leave the side stream un-joined (see mi_unet_plan_defer_join)
+  bool last_deferred;  // the last backward call ended with the side stream ordered behind it, not joined
   std::vector<hipEvent_t> sync_pool;
   size_t sync_used;
 
@@ -206,14 +207,18 @@ __global__ void noop_kernel() {}
 // the two-stream backward ran slower than the one-stream one).  So the side stream is CHOSEN: of a
 // handful of new streams, the first on which a trivial kernel finishes while a 50 us spin kernel
 // still occupies the caller's stream.  If none does, backward stays on one stream.
-// The choice is made once per (device, caller stream) and shared by every plan of the process; the
-// rejected candidates are kept (a handful of idle streams) rather than destroyed.
+// The choice is made once per (device, caller stream) and shared by every plan of the process (the
+// one piece of process-wide state in the library: a cache of measurements, holding one stream per
+// pair for the life of the process).  Rejected candidates are destroyed once the choice is made --
+// not before, so that a later candidate is never handed the slot of an earlier one.
 static std::mutex g_side_mutex;
 static std::map<std::pair<int, hipStream_t>, hipStream_t> g_side_choice;
 static hipStream_t choose_side_stream(hipStream_t main) {
   constexpr int kCandidates = 8;
   hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
   hipStream_t chosen = nullptr;
+  hipStream_t rejected[kCandidates];
+  int n_rejected = 0;
   int tried = 0;
   if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess) {
     for (; tried < kCandidates && !chosen; ++tried) {
@@ -228,8 +233,10 @@ static hipStream_t choose_side_stream(hipStream_t main) {
       float ta = 0.f, tb = 0.f;
       ok = ok && hipEventElapsedTime(&ta, e0, ea) == hipSuccess && hipEventElapsedTime(&tb, e0, eb) == hipSuccess;
       if (ok && tb < 0.5f * ta) chosen = c;
+      else rejected[n_rejected++] = c;
     }
   }
+  for (int i = 0; i < n_rejected; ++i) (void)hipStreamDestroy(rejected[i]);   // idle: both test kernels were waited for
   (void)hipGetLastError();
   if (e0) (void)hipEventDestroy(e0);
   if (ea) (void)hipEventDestroy(ea);
@@ -279,6 +286,20 @@ int join_side(Run& r) {
   int rc = check_hip(hipEventRecord(e, P->side), "unet_backward: event record");
   if (rc == MI_OK) rc = check_hip(hipStreamWaitEvent(r.s, e, 0), "unet_backward: stream wait");
   return rc;
+}
+
+// Bucketed caller (defer_join on, more segments to come): the side stream catches up with this call's
+// main-stream work instead of the main stream waiting for the weight gradients; the caller reduces the
+// finished range behind the side stream and the dgrad chain of the next call starts at once.  True when
+// the side stream is now ordered behind everything the call enqueued (also when the call put nothing on
+// it, as a head-only call does); false when there is no usable side stream -- the caller of this
+// function then joins as usual and the range is complete in the caller's stream order.
+bool defer_to_side(Run& r, int seg_hi) {
+  mi_unet_plan* P = r.P;
+  if (!P->defer_join || seg_hi >= (int)P->segs.size()) return false;
+  if (fork_side(r) == r.s) return false;
+  P->last_deferred = true;
+  return true;
 }
 
 #define RUN(expr)                 \
@@ -469,7 +490,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   P->forward_done = false;
   P->profile = false;
   P->events_used = 0;
-  P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0; P->defer_join = false; P->side_owned = false;
+  P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0; P->defer_join = false; P->side_owned = false; P->last_deferred = false;
   P->cap_stream = nullptr; P->graph_mode = -1;
   P->h.resize(L + 1); P->w.resize(L + 1);
   P->h[0] = d.height; P->w[0] = d.width;
@@ -989,13 +1010,7 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
     RUN(flush_wgrads(r, seg));
   }
   if (!(phases & PH_BODY)) return MI_OK;
-  if (P->defer_join && seg_hi < (int)P->segs.size() && P->side_busy) {
-    // bucketed caller: the side stream catches up with this call's main-stream work instead of the
-    // main stream waiting for the weight gradients; the caller reduces the finished range on the
-    // side stream and the dgrad chain of the next call starts at once.  The last call joins.
-    fork_side(r);
-    return MI_OK;
-  }
+  if (defer_to_side(r, seg_hi)) return MI_OK;
   return join_side(r);
 }
 }  // namespace
@@ -1011,9 +1026,14 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
   MI_REQUIRE(seg_lo >= 0 && seg_hi <= nseg && seg_lo <= seg_hi, "unet_backward: bad segment range");
   MI_REQUIRE(!P->d.need_input_grad || dx_nchw || seg_hi < nseg, "unet_backward: dx buffer required");
   hipStream_t s = (hipStream_t)stream;
+  P->last_deferred = false;
   if (seg_lo == 0 && seg_hi > 0)
     RUN(backward_phases(P, dpred_nchw, params_flat, ws, grads, alpha, beta, 0, 1, dx_nchw, s, PH_IN));
   const int lo = seg_lo > 1 ? seg_lo : 1;
+  if (lo >= seg_hi && seg_hi > seg_lo) {     // a head-only call: nothing ran on the side stream, order it all the same
+    Run r{P, (char*)ws, params_flat, s, 0};
+    (void)defer_to_side(r, seg_hi);
+  }
   if (lo < seg_hi) {
     const std::vector<uint64_t> key = {2u, (uint64_t)(uintptr_t)params_flat, (uint64_t)(uintptr_t)ws,
                                        (uint64_t)(uintptr_t)grads, fbits(alpha), fbits(beta), (uint64_t)lo, (uint64_t)seg_hi};
@@ -1034,6 +1054,12 @@ void* mi_unet_plan_side_stream(mi_unet_plan* P, mi_stream main) {
   if (!P || P->profile) return nullptr;
   ensure_side(P, (hipStream_t)main);
   return (void*)P->side;
+}
+int mi_unet_plan_last_call_deferred(const mi_unet_plan* P) { return P && P->last_deferred ? 1 : 0; }
+int mi_unet_plan_prepare(mi_unet_plan* P, mi_stream caller_stream) {
+  MI_REQUIRE(P, "unet_plan_prepare: null plan");
+  ensure_side(P, (hipStream_t)caller_stream);
+  return MI_OK;
 }
 
 }  // extern "C"

@@ -14,6 +14,12 @@ group's communication stream waits for the compute stream at that point and the
 collective overlaps with the remaining backward kernels.  Over xGMI (point-to-point
 links) a ring all-reduce is bound by one link, so buckets are few and large (default
 8 MiB) and the tiny early-encoder tail rides in the last bucket.
+
+Collective per bucket (``mode``): ``"allreduce"`` issues one all-reduce and leaves the
+algorithm to RCCL; ``"rs_ag"`` issues a reduce-scatter followed by an all-gather of the
+bucket (each rank owns 1/world of it in between), the direct form that can drive all
+point-to-point links of a fully connected node at once.  The two give every rank the same
+sums; which is faster on a given node is a measurement (``bench.py --collective``).
 """
 from __future__ import annotations
 
@@ -88,9 +94,16 @@ def plan_buckets(segments: List[Tuple[int, int]], bucket_bytes: int) -> List[Tup
 class GradientReducer:
     """Averages a flat gradient buffer across the process group, bucket by bucket."""
 
-    def __init__(self, process_group=None, bucket_bytes: int = 8 << 20, force: bool = False):
+    MODES = ("allreduce", "rs_ag")
+
+    def __init__(self, process_group=None, bucket_bytes: int = 8 << 20, force: bool = False, mode: Optional[str] = None):
         """``force`` keeps the bucketed path (and its collectives) active in a one-rank group:
-        a way to exercise the RCCL calls on a single GPU."""
+        a way to exercise the RCCL calls on a single GPU.  ``mode`` picks the collective per bucket
+        (default "allreduce", or the UNET_TM_COLLECTIVE environment variable)."""
+        mode = mode or os.environ.get("UNET_TM_COLLECTIVE") or "allreduce"
+        if mode not in self.MODES:
+            raise ValueError(f"GradientReducer: unknown mode {mode!r} (expected one of {self.MODES})")
+        self.mode = mode
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()
@@ -112,16 +125,37 @@ class GradientReducer:
         return b
 
     def reduce_async(self, flat_slice: torch.Tensor) -> None:
-        if self.world > 1 or self.force:
-            if _DEBUG:
-                print(f"[dp rank {dist.get_rank(self.group)}] all_reduce {flat_slice.numel()} elements", flush=True)
+        """Start summing ``flat_slice`` (a contiguous fp32 range of the flat gradient buffer) across
+        the group, in place; ``wait_all`` completes it."""
+        if not (self.world > 1 or self.force):
+            return
+        if _DEBUG:
+            print(f"[dp rank {dist.get_rank(self.group)}] {self.mode} {flat_slice.numel()} elements", flush=True)
+        if self.mode == "allreduce":
             self._pending.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # reduce-scatter + all-gather over the part of the bucket that splits evenly into `world`
+        # shards of whole 8-element (32-byte) groups; the few elements left over (segment ranges are
+        # multiples of 64 elements, so there are none for world sizes dividing 8) ride in a small
+        # all-reduce.  Collectives of one group run in issue order on the group's stream, so the
+        # all-gather needs no wait on the reduce-scatter in between.
+        n = flat_slice.numel()
+        rank = dist.get_rank(self.group)
+        shard = n // (8 * self.world) * 8
+        body = shard * self.world
+        if shard > 0:
+            mine = flat_slice[rank * shard:(rank + 1) * shard]
+            self._pending.append(dist.reduce_scatter_tensor(mine, flat_slice[:body], op=dist.ReduceOp.SUM,
+                                                            group=self.group, async_op=True))
+            self._pending.append(dist.all_gather_into_tensor(flat_slice[:body], mine, group=self.group, async_op=True))
+        if body < n:
+            self._pending.append(dist.all_reduce(flat_slice[body:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait_all(self) -> None:
         for i, w in enumerate(self._pending):
             w.wait()
             if _DEBUG:
-                print(f"[dp rank {dist.get_rank(self.group)}] bucket {i} done", flush=True)
+                print(f"[dp rank {dist.get_rank(self.group)}] collective {i} done", flush=True)
         self._pending.clear()
 
     def reduce_flat(self, flat: torch.Tensor, segments: List[Tuple[int, int]], prescaled: bool = False) -> None:

@@ -26,7 +26,10 @@ import torch.nn as nn
 from .._lib import MI_FWD_REPACK, MI_FWD_TRAIN, UNetDesc, check, lib
 from ..ops import mi_dtype, torch_dtype
 
-DEFAULT_COMPUTE_DTYPE = os.environ.get("UNET_TM_DTYPE", "bf16")
+# The reference trains and evaluates in fp32 with no autocast (train.py:495-498), so the drop-in default
+# is the exact-fp32 path; bf16 storage + bf16 MFMA is opt-in (compute_dtype="bf16", cfg.compute_dtype,
+# or UNET_TM_DTYPE=bf16 in the environment).
+DEFAULT_COMPUTE_DTYPE = os.environ.get("UNET_TM_DTYPE", "fp32")
 
 
 class _Plan:
@@ -116,6 +119,26 @@ class _Lease:
             pass
 
 
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(device: torch.device):
+    """Context that makes ``device`` the current one; free when it already is (the usual case)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 def _contiguous_strides(shape):
     st = [1] * len(shape)
     for i in range(len(shape) - 2, -1, -1):
@@ -155,8 +178,9 @@ class UNet(nn.Module):
     """U-Net for traffic-matrix prediction, MI355X-native.
 
     Arguments are the reference's (models/unet2d.py:9-15) plus ``compute_dtype``:
-    ``"bf16"`` (bf16 storage + bf16 MFMA with fp32 accumulation; parameters, gradients and
-    optimiser state stay fp32) or ``"fp32"`` (exact-fp32 MFMA throughout)."""
+    ``"fp32"`` (the default, as the reference computes: exact-fp32 MFMA throughout) or ``"bf16"``
+    (bf16 storage + bf16 MFMA with fp32 accumulation; parameters, gradients and optimiser state
+    stay fp32)."""
 
     def __init__(self, in_channels=1, out_channels=1, features=(32, 64, 128, 256), out_size=None,
                  compute_dtype=None):
@@ -316,8 +340,11 @@ class UNet(nn.Module):
             flags |= MI_FWD_REPACK
         oh, ow = plan.out_hw
         pred = torch.empty((plan.B, self.out_channels, oh, ow), device=x.device, dtype=torch.float32)
-        check(lib().mi_unet_forward(plan.handle, x.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes,
-                                    pred.data_ptr(), flags, torch.cuda.current_stream().cuda_stream), "unet_forward")
+        # the library launches on the CURRENT device (its zero page, its stream choice): make that the tensors' device
+        with _on_device(x.device):
+            check(lib().mi_unet_forward(plan.handle, x.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes,
+                                        pred.data_ptr(), flags, torch.cuda.current_stream(x.device).cuda_stream),
+                  "unet_forward")
         if flags & MI_FWD_REPACK:
             plan.packed_version, plan.packed_train = version, train
         self._last_pred = pred
@@ -329,6 +356,11 @@ class UNet(nn.Module):
         """Run backward over all segments into ``out`` (a flat fp32 buffer; allocated when
         None).  With a gradient reducer attached, each finished bucket's all-reduce is
         started while the remaining segments are still being enqueued."""
+        with _on_device(self._flat.device):
+            return self._backward_on_device(plan, dpred, out, beta, alpha)
+
+    def _backward_on_device(self, plan: _Plan, dpred: torch.Tensor, out: Optional[torch.Tensor], beta: float,
+                            alpha: float):
         flat = self._flat
         dpred = dpred.contiguous()
         if dpred.dtype != torch.float32:
@@ -347,7 +379,7 @@ class UNet(nn.Module):
         dx = None
         if plan.need_input_grad:
             dx = torch.empty((plan.B, self.in_channels, plan.H, plan.W), device=flat.device, dtype=torch.float32)
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
         L = lib()
         dp = self._dp
         if dp is None:
@@ -370,7 +402,9 @@ class UNet(nn.Module):
                 check(L.mi_unet_backward(plan.handle, dpred.data_ptr(), flat.data_ptr(), plan.ws.data_ptr(),
                                          plan.ws_bytes, out.data_ptr(), alpha, beta, seg_lo, seg_hi,
                                          dx.data_ptr() if dx is not None else None, stream), "unet_backward")
-                if ext is not None and seg_hi < plan.n_segments:
+                # the library says where the finished range is complete: behind the side stream (deferred
+                # join) or, when the call joined the streams, in the current stream's order
+                if ext is not None and L.mi_unet_plan_last_call_deferred(plan.handle):
                     with torch.cuda.stream(ext):
                         dp.reduce_async(out[lo:hi])
                 else:

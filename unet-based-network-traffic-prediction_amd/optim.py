@@ -1,5 +1,10 @@
 """``FusedAdam``: ``torch.optim.Adam`` semantics (train.py:497: default betas/eps, no weight
-decay, no amsgrad) as one HIP kernel launch over the model's flat parameter buffer."""
+decay, no amsgrad) as one HIP kernel launch over the model's flat parameter buffer.
+
+State lives where ``torch.optim.Adam`` keeps it -- ``self.state[p]`` with the keys ``step``,
+``exp_avg`` and ``exp_avg_sq`` -- so ``state_dict()`` / ``load_state_dict()`` round-trip and
+interchange with the stock optimizer.  On the flat path the two moment tensors of every
+parameter are views of one flat buffer each."""
 from __future__ import annotations
 
 import torch
@@ -9,12 +14,15 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, model=None):
+        """``model`` is accepted for compatibility and not needed: every step bumps the version
+        counter of the parameters it wrote, which is what the U-Net module watches to refresh its
+        packed weights."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = grad_scale
-        self._model = model     # optional: told when parameters change behind torch's back
-        self._flat_state = {}
+        self._model = model
+        self._flat_state = {}      # per group: step count, flat moment buffers, cached layout
 
     @staticmethod
     def _flat_span(params, attr):
@@ -36,6 +44,27 @@ class FusedAdam(torch.optim.Optimizer):
         """fp32 1-D tensor over the whole storage ``t`` lives in (the flat buffer it is a view of)."""
         st = t.untyped_storage()
         return torch.empty(0, dtype=torch.float32, device=t.device).set_(st, 0, (st.nbytes() // 4,))
+
+    def _written(self, params) -> None:
+        """The kernel wrote the parameters through raw pointers: bump their version counters, as an
+        in-place torch op would have (the U-Net module re-packs its MFMA weight images when the
+        versions move; autograd's saved-tensor checks see the write too)."""
+        torch._C._increment_version(params)
+        if self._model is not None:
+            self._model.mark_parameters_changed()
+
+    def _group_step(self, gi, group) -> dict:
+        """The group's running record; the step count is taken from ``self.state`` the first time
+        (a loaded checkpoint continues its bias correction)."""
+        st = self._flat_state.get(gi)
+        if st is None:
+            step = 0
+            for p in group["params"]:
+                ps = self.state.get(p)
+                if ps and "step" in ps:
+                    step = max(step, int(float(ps["step"])))
+            st = self._flat_state[gi] = {"step": step}
+        return st
 
     def _step_cached(self, gi, group) -> bool:
         """The usual step: same parameter tensors at the same addresses as last time, every gradient
@@ -73,7 +102,24 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         ops.adam_step(flat_p, flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2, group["eps"], st["step"],
                       self.grad_scale)
+        self._written(params)
         return True
+
+    def _adopt_flat_moments(self, st, params, pspan, n, device) -> None:
+        """Flat moment buffers for the range; whatever ``self.state`` already holds for a parameter
+        (a loaded checkpoint, steps taken tensor by tensor) is carried into its slice, and from
+        here on ``self.state[p]`` holds views of the flat buffers."""
+        m = torch.zeros(n, device=device, dtype=torch.float32)
+        v = torch.zeros(n, device=device, dtype=torch.float32)
+        for p in params:
+            o = (p.data_ptr() - pspan[0]) // 4
+            mv, vv = m[o:o + p.numel()].view(p.shape), v[o:o + p.numel()].view(p.shape)
+            ps = self.state[p]
+            if "exp_avg" in ps:
+                mv.copy_(ps["exp_avg"])
+                vv.copy_(ps["exp_avg_sq"])
+            ps["exp_avg"], ps["exp_avg_sq"] = mv, vv
+        st["m"], st["v"] = m, v
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -94,7 +140,7 @@ class FusedAdam(torch.optim.Optimizer):
             pspan = self._flat_span(params, None)
             gspan = self._flat_span(params, "grad")
             flat_ok = pspan is not None and gspan is not None and len(params) == len(group["params"])
-            st = self._flat_state.setdefault(gi, {"step": 0})
+            st = self._group_step(gi, group)
             st["step"] += 1
             if flat_ok:
                 n = (pspan[1] - pspan[0]) // 4
@@ -102,25 +148,46 @@ class FusedAdam(torch.optim.Optimizer):
                 flat_g = self._storage_as_flat(params[0].grad)
                 po = (pspan[0] - flat_p.data_ptr()) // 4
                 go = (gspan[0] - flat_g.data_ptr()) // 4
-                if "m" not in st or st["m"].numel() != n:
-                    st["m"] = torch.zeros(n, device=flat_p.device, dtype=torch.float32)
-                    st["v"] = torch.zeros(n, device=flat_p.device, dtype=torch.float32)
+                if "m" not in st or st["m"].numel() != n or st.get("m_base") != pspan[0]:
+                    self._adopt_flat_moments(st, params, pspan, n, flat_p.device)
+                    st["m_base"] = pspan[0]
                 ops.adam_step(flat_p[po:po + n], flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2,
                               group["eps"], st["step"], self.grad_scale)
                 # remember the layout: later steps only confirm that nothing moved (see _step_cached)
                 st["layout"] = (tuple(id(p) for p in group["params"]), params, pspan[0],
                                 [p.data_ptr() - pspan[0] for p in params], flat_p[po:po + n])
             else:
+                # tensor by tensor, on the same moments (views of the flat buffers if the flat path ran before)
+                st.pop("layout", None)
                 for p in params:
                     ps = self.state[p]
-                    if "m" not in ps:
-                        ps["m"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                        ps["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    if "exp_avg" not in ps:
+                        ps["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        ps["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     g = p.grad.contiguous()
                     if not p.is_contiguous():
                         raise RuntimeError("FusedAdam needs contiguous parameters")
-                    ops.adam_step(p, g, ps["m"], ps["v"], group["lr"], b1, b2, group["eps"], st["step"],
+                    ops.adam_step(p, g, ps["exp_avg"], ps["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"],
                                   self.grad_scale)
-        if self._model is not None:
-            self._model.mark_parameters_changed()
+            self._written(params)
         return loss
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """torch.optim.Adam's format: per parameter ``step`` (a float tensor), ``exp_avg``,
+        ``exp_avg_sq``."""
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat_state.get(gi)
+            if not st:
+                continue
+            for p in group["params"]:
+                ps = self.state.get(p)
+                if ps and "exp_avg" in ps:
+                    ps["step"] = torch.tensor(float(st["step"]))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # the loaded moments are fresh tensors: the next step re-adopts them into flat buffers and
+        # continues from the loaded step count
+        self._flat_state = {}
