@@ -7,7 +7,7 @@ may import this file; nothing in the product package does.
 Parity status: PINNED.  ``tests/golden/make_golden_input.py`` runs the reference's own
 ``utils/image_transform.py`` and ``dataset.py`` functions (and scikit-learn's MinMaxScaler, the
 third-party class the reference calls) on a seeded series and stores their outputs;
-``tests/test_oracle_golden.py`` requires this restatement to reproduce them exactly
+``tests/test_input_oracle.py`` requires this restatement to reproduce them exactly
 (``numpy.array_equal``).
 
 What is restated (reference file:line):

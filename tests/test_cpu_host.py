@@ -203,3 +203,94 @@ def test_data_parallel_average_equals_global_batch_gradient(tmp_path):
         got = r0["flat"][off:off + gfull[name].numel()].reshape(gfull[name].shape)
         err = (got - gfull[name]).norm() / (gfull[name].norm() + 1e-30)
         assert err < 5e-6, (name, err.item())
+
+
+def _collective_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import types
+    import unet_amd
+    torch.set_num_threads(2)
+    unet_amd.init_process_group_from_env(backend="gloo")
+    L = unet_amd.lib()
+    rc, h = make_plan(L, 12, 1, (32, 64, 128, 256), 4, 32, 32)          # the default 4-level network
+    assert rc == 0
+    segs, flat_n = plan_segments(L, h), L.mi_unet_plan_flat_elems(h)
+    L.mi_unet_plan_destroy(h)
+    plan = types.SimpleNamespace(segments=segs)
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(flat_n, generator=g)
+    out = {}
+    for mode in unet_amd.GradientReducer.MODES:
+        red = unet_amd.GradientReducer(bucket_bytes=8 << 20, mode=mode)
+        buckets = red.buckets_for(plan)
+        assert len(buckets) >= 3 and buckets[0][0] == 0 and buckets[-1][1] == len(segs)
+        flat = mine * red.grad_prescale                                  # what backward's alpha does on the device
+        covered = 0
+        for (seg_lo, seg_hi, lo, hi) in buckets:                         # the order the backward pass produces them in
+            red.reduce_async(flat[lo:hi])
+            covered += hi - lo
+        red.wait_all()
+        assert covered == flat_n and not red._pending
+        out[mode] = flat
+    # an odd-sized range: the part that does not split into whole shards rides in its own all-reduce
+    red = unet_amd.GradientReducer(mode="rs_ag")
+    odd = (mine[:1003] * 0.5).clone()
+    red.reduce_async(odd)
+    red.wait_all()
+    out["odd"] = odd
+    torch.save(out, os.path.join(out_dir, f"coll{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_reducer_modes_agree_in_backward_bucket_order(tmp_path):
+    """World size 2 over gloo on CPU tensors: GradientReducer.reduce_async / wait_all driven through the
+    bucket order of the default 4-level plan, once per collective mode.  All-reduce and reduce-scatter +
+    all-gather must leave every rank with the same averaged buffer."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_collective_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "coll0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "coll1.pt"))
+    n = r0["allreduce"].numel()
+    expect = 0.5 * (torch.randn(n, generator=torch.Generator().manual_seed(100))
+                    + torch.randn(n, generator=torch.Generator().manual_seed(101)))
+    for mode in ("allreduce", "rs_ag"):
+        assert torch.equal(r0[mode], r1[mode]), mode
+        assert torch.allclose(r0[mode], expect, rtol=0, atol=1e-6), mode
+    assert torch.equal(r0["allreduce"], r0["rs_ag"])                   # two-operand sums: the same bits either way
+    assert torch.equal(r0["odd"], r1["odd"]) and torch.allclose(r0["odd"], expect[:1003], atol=1e-6)
+    with pytest.raises(ValueError, match="unknown mode"):
+        import unet_amd
+        unet_amd.GradientReducer(mode="ring")
+
+
+def test_bench_launches_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher around it starts N workers through
+    torch.distributed.run before touching a GPU, and refuses clearly when the machine has fewer GPUs."""
+    import types
+    import bench
+    monkeypatch.delenv("RANK", raising=False)
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    args = types.SimpleNamespace(gpus=4)
+    rc = bench.self_launch(args, ["--gpus", "4", "--steps", "3"], device_count=lambda: 8, run=fake_run)
+    assert rc == 7                                                      # the workers' status is the bench's status
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen.clear()
+    rc = bench.self_launch(args, ["--gpus", "4"], device_count=lambda: 1, run=fake_run)
+    assert rc != 0 and not seen
+    assert "needs 4 GPUs" in capsys.readouterr().err
+    # the whole entry point: no launcher environment, one visible GPU at most in this container
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"])
+    assert e.value.code not in (0, None)

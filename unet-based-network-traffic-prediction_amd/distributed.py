@@ -38,9 +38,12 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
     ``backend`` defaults to "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".
     Returns (rank, world_size, local_rank).
 
-    Rehearsal on a box with fewer GPUs than ranks: ``UNET_TM_DIST_BACKEND=gloo`` selects the
-    backend and ``UNET_TM_FORCE_DEVICE=<index>`` puts every rank on that one device (RCCL itself
-    refuses two ranks per GPU; gloo stages through host memory)."""
+    ``UNET_TM_DIST_BACKEND`` selects another backend and ``UNET_TM_FORCE_DEVICE=<index>`` another
+    device.  Several gloo ranks sharing ONE GPU is not a supported rehearsal: ProcessGroupGloo stages
+    device tensors through host memory, and with two processes on one device its asynchronous
+    all-reduce stalls intermittently inside ``Work.wait()`` even in a stock-torch program with no
+    code of this package in it (RCCL itself refuses two ranks per GPU).  Multi-rank logic is covered
+    by gloo on CPU tensors, the RCCL calls by a one-rank group on the GPU."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -137,16 +140,22 @@ class GradientReducer:
         # reduce-scatter + all-gather over the part of the bucket that splits evenly into `world`
         # shards of whole 8-element (32-byte) groups; the few elements left over (segment ranges are
         # multiples of 64 elements, so there are none for world sizes dividing 8) ride in a small
-        # all-reduce.  Collectives of one group run in issue order on the group's stream, so the
-        # all-gather needs no wait on the reduce-scatter in between.
+        # all-reduce.  RCCL runs the collectives of one group in issue order on the group's stream, so
+        # the all-gather is simply enqueued behind the reduce-scatter; a host backend (gloo) runs
+        # asynchronous operations on worker threads in no particular order, so there the
+        # reduce-scatter is waited for first.
         n = flat_slice.numel()
         rank = dist.get_rank(self.group)
         shard = n // (8 * self.world) * 8
         body = shard * self.world
         if shard > 0:
             mine = flat_slice[rank * shard:(rank + 1) * shard]
-            self._pending.append(dist.reduce_scatter_tensor(mine, flat_slice[:body], op=dist.ReduceOp.SUM,
-                                                            group=self.group, async_op=True))
+            rs = dist.reduce_scatter_tensor(mine, flat_slice[:body], op=dist.ReduceOp.SUM, group=self.group,
+                                            async_op=True)
+            if flat_slice.is_cuda:
+                self._pending.append(rs)
+            else:
+                rs.wait()
             self._pending.append(dist.all_gather_into_tensor(flat_slice[:body], mine, group=self.group, async_op=True))
         if body < n:
             self._pending.append(dist.all_reduce(flat_slice[body:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
