@@ -106,6 +106,20 @@ int mi_conv3x3_wgrad(const void* x, int x_cstride, int x_coff,
                      float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes,
                      int B, int H, int W, int Cin, int split, int Cout, int dtype, mi_stream s);
 size_t mi_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int split, int Cout, int dtype);
+/* The same weight gradient for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Identical to mi_conv3x3_wgrad -- same kernels, same fixed-order combine, bit-identical dW/db --
+ * except that the partial sums live in a scratch array built into the library (one copy per GPU,
+ * held until the process ends) instead of a caller workspace, and the call performs no allocation
+ * of any kind.  Shapes whose mi_conv3x3_wgrad_ws_bytes() exceeds
+ * mi_conv3x3_wgrad_static_max_bytes() (32 MiB) are rejected with MI_ESIZE.  All calls on one GPU
+ * share that GPU's scratch: calls that may overlap on one GPU (different streams, different
+ * threads) race; order them on one stream or with events. */
+int mi_conv3x3_wgrad_static(const void* x, int x_cstride, int x_coff,
+                            const void* dy, int dy_cstride, int dy_coff,
+                            float* dW, float* db, float alpha, float beta,
+                            int B, int H, int W, int Cin, int split, int Cout, int dtype, mi_stream s);
+size_t mi_conv3x3_wgrad_static_max_bytes(void);
 
 /* ------------------------------------------------------------------ A2: 2x2 max-pool */
 /* nn.MaxPool2d(2,2), models/unet2d.py:22/:68.  Output is (B, H/2, W/2, C) (floor). */

@@ -39,6 +39,8 @@ SIGNATURES = {
     "mi_conv3x3_dgrad": (_i, _VIEW + [_p] + _VIEW + _VIEW + [_i] * 7 + [_p]),
     "mi_conv3x3_wgrad": (_i, _VIEW + _VIEW + [_p, _p, _f, _f, _p, _sz] + [_i] * 7 + [_p]),
     "mi_conv3x3_wgrad_ws_bytes": (_sz, [_i] * 7),
+    "mi_conv3x3_wgrad_static": (_i, _VIEW + _VIEW + [_p, _p, _f, _f] + [_i] * 7 + [_p]),
+    "mi_conv3x3_wgrad_static_max_bytes": (_sz, []),
     "mi_maxpool2_fwd": (_i, _VIEW + _VIEW + [_i] * 5 + [_p]),
     "mi_maxpool2_bwd": (_i, _VIEW + _VIEW + _VIEW + _VIEW + [_i] * 6 + [_p]),
     "mi_convt2x2_fwd": (_i, _VIEW + [_p, _p] + _VIEW + [_i] * 6 + [_p]),

@@ -50,6 +50,31 @@ const void* zero_page() {
   return g_zero_ptr[dev];
 }
 
+// ---- static scratch: the partial-sum slabs of mi_conv3x3_wgrad_static (callers that cannot allocate).
+// A file-scope device array; every GPU the library runs on holds its own copy, at its own address,
+// until the process ends.  In host code the array's NAME is only a stand-in: the address the kernels
+// get is resolved once per device with hipGetSymbolAddress, with that device current.
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[64] = {nullptr};
+static int static_scratch(void** out) {
+  int dev = 0;
+  int rc = check_hip(hipGetDevice(&dev), "static scratch: current device");
+  if (rc) return rc;
+  MI_REQUIRE(dev >= 0 && dev < 64, "static scratch: device index out of range");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    rc = check_hip(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), "static scratch: hipGetSymbolAddress");
+    if (rc) return rc;
+    MI_REQUIRE(p != nullptr && ((uintptr_t)p & 255) == 0, "static scratch: unusable device address");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return MI_OK;
+}
+
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** name) {
@@ -426,6 +451,28 @@ int mi_conv3x3_wgrad(const void* x, int xcs, int xco, const void* dy, int ycs, i
   MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW && ws, "conv3x3_wgrad: bad arguments");
   return run_conv3x3_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, ws_bytes, B, H, W, Cin, split, Cout,
                            dtype, (hipStream_t)s, nullptr, nullptr);
+}
+
+size_t mi_conv3x3_wgrad_static_max_bytes(void) { return kStaticScratchBytes; }
+int mi_conv3x3_wgrad_static(const void* x, int xcs, int xco, const void* dy, int ycs, int yco, float* dW, float* db,
+                            float alpha, float beta, int B, int H, int W, int Cin, int split, int Cout, int dtype,
+                            mi_stream s) {
+  MI_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && dW, "conv3x3_wgrad_static: bad arguments");
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_BF16, "conv3x3_wgrad_static: bad dtype");
+  const size_t need = mi_conv3x3_wgrad_ws_bytes(B, H, W, Cin, split, Cout, dtype);
+  if (need > kStaticScratchBytes) {
+    char msg[200];
+    snprintf(msg, sizeof msg, "conv3x3_wgrad_static: this shape needs %zu bytes of partial sums, the static scratch holds "
+             "%zu; use mi_conv3x3_wgrad with a caller-provided workspace", need, kStaticScratchBytes);
+    return fail(MI_ESIZE, msg);
+  }
+  void* ws = nullptr;
+  int rc = static_scratch(&ws);
+  if (rc) return rc;
+  // every partial slab and row sum the combine reads is written by the weight-gradient kernel of
+  // this same call, so nothing in the scratch has to start at zero
+  return run_conv3x3_wgrad(x, xcs, xco, dy, ycs, yco, dW, db, alpha, beta, ws, kStaticScratchBytes, B, H, W, Cin, split,
+                           Cout, dtype, (hipStream_t)s, nullptr, nullptr);
 }
 
 int mi_maxpool2_fwd(const void* x, int xcs, int xco, void* y, int ycs, int yco, int B, int H, int W, int C, int dtype,
