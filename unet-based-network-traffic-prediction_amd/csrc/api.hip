@@ -27,6 +27,7 @@ int launch_igemm_f32(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
+int launch_dconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
 bool tconv_eligible(const IgemmArgs& a);
@@ -114,6 +115,10 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
       }
       h.W = a.Wi; h.R = R; h.G = G; h.pitch = (a.Wi + 2 + 7) / 8 * 8; h.HR = G * (R + 2) * h.pitch; h.bands = bands;
       h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
+      if (dtype == MI_BF16) {      // the DMA-fed kernel where it applies, else the register-staged one
+        const int rc = launch_dconv_bf16(h, s, name);
+        if (rc != -1000) return rc;
+      }
       return dtype == MI_BF16 ? launch_hconv_bf16(h, s, name) : launch_hconv_f32(h, s, name);
     }
   }
