@@ -41,6 +41,7 @@ struct DconvArgs {
   int pa;           // DMA pieces per pixel tile = ceil(HR / 16)
   int remap;        // XCD-aware block order (gx % 8 == 0)
   int gx, ny;
+  FastDiv d_ny, d_gx;
   unsigned m_grp, m_pitch;   // ceil(2^20 / ((R+2)*pitch)), ceil(2^20 / pitch): exact 24-bit division of halo slot indices
 };
 
@@ -71,6 +72,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
 constexpr unsigned kDmaOob = 0x80000000u;
+// Value of lane+N inside the lane's 16-lane row (DPP row_shl:N); lanes whose source falls outside the row keep their own.
+template <int N> __device__ __forceinline__ float row_shl(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, false));
+}
 template <typename V> __device__ __forceinline__ void pin_scalar(V v) { asm volatile("" ::"s"(v)); }
 template <typename... A> __device__ __forceinline__ void pin_scalars(A... v) { (pin_scalar(v), ...); }
 
@@ -93,11 +98,12 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   int bx, by;
   if (d.remap) {      // the ny channel tiles of one pixel tile share an XCD (blocks b and b+8 do)
     const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
-    by = k % d.ny; bx = (k / d.ny) * 8 + xcd;
-  } else { bx = blockIdx.x % d.gx; by = blockIdx.x / d.gx; }
+    const int kq = (int)fdiv((uint32_t)k, d.d_ny);
+    by = k - kq * d.ny; bx = kq * 8 + xcd;
+  } else { by = (int)fdiv(blockIdx.x, d.d_gx); bx = (int)blockIdx.x - by * d.gx; }
   const int n0 = by * BN;
   const int grp_rows = (a.R + 2) * a.pitch;
-  const int my_tiles = (a.ntiles - bx + d.gx - 1) / d.gx;
+  const int my_tiles = (int)fdiv((uint32_t)(a.ntiles - bx + d.gx - 1), d.d_gx);
   const int nstages = my_tiles * a.nchunks;       // (tile, chunk) pairs of this workgroup, in order
   if (nstages <= 0) return;
   const int NA = d.na;
@@ -114,13 +120,31 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #ifdef MI_DCONV_DIAG
     const long long r_zeroed = r_entry;
 #endif
+    __builtin_amdgcn_s_setprio(3);    // the loaders' few instructions go first: everything else waits for their data
     const T* __restrict__ in = (const T*)a.in;
     const T* __restrict__ wp = (const T*)a.w;
     const int lw = wave - 8;
+    // weights first: their offsets are cheap, and the loads fly while the pixel-tile geometry is worked out
+    const int l4 = lane >> 2, cpos = lane & 3;
+    unsigned w_voff[W_IT];            // byte offset of this lane's weight source for channel chunk 0
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int q = lw + 4 * i, row = q * 16 + l4;
+      const int tap = row / BN, n = row - tap * BN;
+      w_voff[i] = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
+    }
+    auto issue_w = [&](int chunk, int wslot) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + chunk * CK);
+      char* dst = smem + d.w_base + wslot * W_BYTES + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i)
+        if (lw + 4 * i < WP) dma16(rs, w_voff[i], dst + i * 4096);
+    };
+    if (resident) { for (int c = 0; c < a.nchunks; ++c) issue_w(c, c); }
+    else issue_w(0, 0);
     // Piece q of a pixel tile covers halo slots [16q, 16q+16): lane L fills chunk position L&3 of
     // slot 16q + (L>>2) with the channel chunk that the swizzle puts there.  Offsets are bytes from
     // (tile's first pixel - one image row): the top halo row of a band lies in the band above.
-    const int l4 = lane >> 2, cpos = lane & 3;
     const int margin = a.W * a.in_cs;
     unsigned a_voff[A_IT];            // byte offset of this lane's source, or out of range (padding slot: zeros)
     unsigned topmask = 0, botmask = 0;   // bit i: piece i of this lane is a top / bottom halo row of a band
@@ -128,6 +152,10 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     int cnt_a = 0;                    // pixel-tile pieces this wave issues per tile
     const unsigned uW = (unsigned)a.W, uR1 = (unsigned)a.R + 1u, RW = (unsigned)(a.R * a.W);
     const bool single = a.bands == 1;
+    // the first tile's pieces are issued as soon as their offsets exist
+    const int band0 = bx - (int)fdiv((uint32_t)bx, a.d_bands) * a.bands;
+    const bool ztop0 = !single && band0 == 0, zbot0 = !single && band0 == a.bands - 1;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(in + ((int64_t)bx * BM * a.in_cs + a.in_co - margin));
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {      // branch-free: 24-bit multiplies and selects only
       const int q = lw + 4 * i;
@@ -144,6 +172,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       const bool any = __builtin_amdgcn_ballot_w64(on) != 0;
       skipmask |= (unsigned)(!any) << i;
       cnt_a += any;
+      if (any) dma16(rs0, ((ztop0 & on & top) | (zbot0 & on & bot)) ? kDmaOob : a_voff[i], smem + q * 1024);
     }
     // all-padding pieces are zeroed in every ring slot, once: no DMA ever writes these bytes
     for (int i = 0; i < A_IT; ++i)
@@ -151,13 +180,6 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll 1
         for (int k = 0; k < NA; ++k) *(u32x4_t*)(smem + k * d.a_slot + (lw + 4 * i) * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
       }
-    unsigned w_voff[W_IT];            // byte offset of this lane's weight source for channel chunk 0
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int q = lw + 4 * i, row = q * 16 + l4;
-      const int tap = row / BN, n = row - tap * BN;
-      w_voff[i] = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
-    }
     auto issue_a = [&](int tile, int chunk, int slot) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + ((int64_t)tile * BM * a.in_cs + a.in_co + chunk * CK - margin));
       char* dst = smem + slot * d.a_slot + lw * 1024;
@@ -174,13 +196,6 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
           if (!((skipmask >> i) & 1)) dma16(rs, ((zmask >> i) & 1) ? kDmaOob : a_voff[i], dst + i * 4096);
       }
     };
-    auto issue_w = [&](int chunk, int wslot) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + chunk * CK);
-      char* dst = smem + d.w_base + wslot * W_BYTES + lw * 1024;
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i)
-        if (lw + 4 * i < WP) dma16(rs, w_voff[i], dst + i * 4096);
-    };
     // load cursor: (tile, chunk, slot) of the next pixel tile to fetch; lstage = tiles issued so far
     int ltile = bx, lchunk = 0, lslot = 0, lstage = 0;
     auto advance_load = [&]() {
@@ -188,16 +203,14 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       if (++lslot == NA) lslot = 0;
       ++lstage;
     };
-    // prologue: tile 0, weights (all chunks when resident), then the tiles that may stay in flight
+    // prologue, continued: the tiles that may stay in flight beyond stage 0
 #ifdef MI_DCONV_DIAG
     const long long r_setup = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    issue_a(ltile, lchunk, lslot); advance_load();
+    advance_load();                    // tile 0 and the weights are on their way
 #ifdef MI_DCONV_DIAG
     const long long r_a0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    if (resident) { for (int c = 0; c < a.nchunks; ++c) issue_w(c, c); }
-    else issue_w(0, 0);
     int ahead = 0;
     while (lstage < NA - 1 && lstage < nstages) { issue_a(ltile, lchunk, lslot); advance_load(); ++ahead; }
 #ifdef MI_DCONV_DIAG
@@ -291,14 +304,23 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   };
   T* __restrict__ out = (T*)a.out;
   const T* __restrict__ mask = (const T*)a.mask;
+  // ReLU mask of the tile (dgrad): fetched at the START of the tile's last stage, so the loads land
+  // behind that stage's MFMAs instead of stalling the epilogue for a round trip to memory
+  constexpr int MV = CPL / 8 > 0 ? CPL / 8 : 1;      // 16-byte vectors per pixel of this lane (CPL >= 8: TN >= 2)
+  bf16x8_t mreg[TM][MV];
+  auto prefetch_mask = [&](int tile) {
+    const T* mtile = mask + (int64_t)tile * BM * a.mask_cs;
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int k = 0; k < MV; ++k) {
+        if (CPL >= 8) mreg[j][k] = *(const bf16x8_t*)(mtile + mask_off[j] + 8 * k);
+        else { const bf16x4_t h = *(const bf16x4_t*)(mtile + mask_off[j]); mreg[j][k] = bf16x8_t{h[0], h[1], h[2], h[3], h[0], h[1], h[2], h[3]}; }
+      }
+  };
   auto epilogue = [&](int tile) {
     T* otile = out + (int64_t)tile * BM * a.out_cs;
     if (mask != nullptr) {
-      // all mask loads first, then all stores: interleaved, every store would wait for its load
-      const T* mtile = mask + (int64_t)tile * BM * a.mask_cs;
-      float mv[TM][CPL];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) load_run(mtile + mask_off[j], mv[j], CPL);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         float v[CPL];
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float x = acc[i][j][q] + biasv[4 * i + q];
-            v[4 * i + q] = mv[j][4 * i + q] > 0.f ? x : 0.f;
+            v[4 * i + q] = (float)mreg[j][(4 * i + q) / 8][(4 * i + q) % 8] > 0.f ? x : 0.f;
           }
         store_run(otile + out_off[j], v, CPL);
       }
@@ -334,6 +356,8 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
         const float x = acc[i][j][q] + biasv[4 * i + q];
         return (a.relu && !(x > 0.f)) ? 0.f : x;
       };
+      // Only the lane of a window's even row and even column stores, and its partners sit at lane+1
+      // and lane+W inside its 16-lane row: two DPP row shifts (VALU) instead of LDS-routed shuffles.
       if (a.W >= 16) {
         float m[CPL];
 #pragma unroll
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float tt = fmaxf(val(i, 0, q), val(i, 1, q));
-            m[4 * i + q] = fmaxf(tt, __shfl_xor(tt, 1, 64));
+            m[4 * i + q] = fmaxf(tt, row_shl<1>(tt));
           }
         if (pool_off[0] >= 0) store_run(ptile + pool_off[0], m, CPL);
       } else {
@@ -353,8 +377,8 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float tt = val(i, j, q);
-              tt = fmaxf(tt, __shfl_xor(tt, a.W, 64));
-              m[4 * i + q] = fmaxf(tt, __shfl_xor(tt, 1, 64));
+              tt = fmaxf(tt, a.W == 8 ? row_shl<8>(tt) : row_shl<4>(tt));
+              m[4 * i + q] = fmaxf(tt, row_shl<1>(tt));
             }
           if (pool_off[j] >= 0) store_run(ptile + pool_off[j], m, CPL);
         }
@@ -380,6 +404,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #endif
     const char* Ab = smem + aslot * d.a_slot;
     const char* Wb = smem + d.w_base + (resident ? chunk : (s & 1)) * W_BYTES;
+    if (mask != nullptr && chunk == a.nchunks - 1) prefetch_mask(tile);
     // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
     frag_t pf[2][TM], wf[2][TN];
     auto read_tap = [&](int tap, int set) {
@@ -447,22 +472,27 @@ int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name) {
   // channel tile: 64 where that still gives every CU a workgroup, else 32 (16 for narrow layers)
   int bn = a.N % 64 == 0 ? 64 : (a.N % 32 == 0 ? 32 : 16);
   if (bn == 64 && a.ntiles * (a.N / 64) < 256 && a.ntiles * (a.N / 32) <= 512) bn = 32;
-  d.ny = a.N / bn;
   d.pa = (a.HR + 15) / 16;
   d.a_slot = d.pa * 1024;
-  const int w_bytes = 9 * bn * 64;
-  // weights: resident when all chunks fit beside at least two pixel-tile slots, else two streaming slots
-  d.w_resident = (int64_t)a.nchunks * w_bytes + 2 * d.a_slot <= kDconvLds;
-  const int w_region = d.w_resident ? a.nchunks * w_bytes : 2 * w_bytes;
-  d.na = (kDconvLds - w_region) / d.a_slot;
-  if (d.na > 6) d.na = 6;
-  if (d.na < 2) return -1000;
+  for (;;) {
+    const int w_bytes = 9 * bn * 64;
+    // weights: resident when all chunks fit beside at least two pixel-tile slots, else two streaming slots
+    d.w_resident = (int64_t)a.nchunks * w_bytes + 2 * d.a_slot <= kDconvLds;
+    const int w_region = d.w_resident ? a.nchunks * w_bytes : 2 * w_bytes;
+    d.na = (kDconvLds - w_region) / d.a_slot;
+    if (d.na > 6) d.na = 6;
+    if (d.na >= 2) break;
+    if (bn == 16) return -1000;
+    bn /= 2;                          // a narrower channel tile leaves room for two pixel-tile slots
+  }
+  d.ny = a.N / bn;
   d.w_base = d.na * d.a_slot;
   int gx = a.ntiles;
   const int cap = (256 + d.ny - 1) / d.ny;
   if (gx > cap) gx = cap;
   d.gx = gx;
   d.remap = gx % 8 == 0;
+  d.d_ny = make_fastdiv(d.ny); d.d_gx = make_fastdiv(gx);
   d.m_grp = ((1u << 20) + (a.R + 2) * a.pitch - 1) / ((a.R + 2) * a.pitch);
   d.m_pitch = ((1u << 20) + a.pitch - 1) / a.pitch;
   dim3 grid(gx * d.ny);
