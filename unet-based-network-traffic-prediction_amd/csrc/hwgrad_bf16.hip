@@ -12,6 +12,10 @@
 // ds_read_b64_tr_b16.  Halo rows are laid out with a pitch that is a multiple of 16 rows:
 // a vertical tap shift then leaves the swizzle bits unchanged and becomes an immediate
 // offset; the three horizontal shifts use three precomputed addresses.
+// The tiles are brought in by FOUR LOADER WAVES (waves 8-11) through buffer LDS-DMA
+// (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass; lanes of padding slots carry
+// an out-of-range offset and write zeros); the eight compute waves only read fragments and issue
+// MFMAs, and meet the loaders at one barrier per tile.
 // Each wave keeps 2 n-tiles x 1 c-tile x 9 taps of accumulators; waves that share an
 // accumulator block split the tile's pixels and are summed through LDS at the end, so a
 // workgroup writes one partial slab; the slabs of the pixel splits are summed by the
@@ -21,7 +25,7 @@
 
 namespace mi {
 
-constexpr int kHwMaxHalo = 640;   // halo rows (pitch-padded) the LDS buffer holds
+constexpr int kHwMaxHalo = 768;   // halo rows (pitch-padded) the LDS buffer holds: 16 images of 4x4 at pitch 8
 
 // dy tile: [256][NB] bf16.  NB = 64 -> 128-byte rows (32-byte column group ^ row bits 1,3);
 // NB = 32 -> 64-byte rows (32-byte column group ^ row bit 3).
@@ -42,7 +46,9 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 }
 
 // Work of workgroup (bx, by, bz) = (n-block, c-block, pixel split) of one layer.
-template <int NB>
+// RP: 4-wide images, halo pitch 8 -- a vertical tap shift of one row flips bit 3 of the halo row, i.e. the
+// swizzle bit: odd ty reads the other 32-byte half (the rule the conv kernels use for these images).
+template <int NB, bool RP>
 __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, const int by, const int bz, char* smem) {
   typedef __bf16 T;
   constexpr int COMBOS = (NB / 32) * 2;        // (n-pair, c-tile) accumulator blocks
@@ -52,69 +58,91 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
   constexpr int X_BYTES = kHwMaxHalo * 64;
   constexpr int STAGE = DY_BYTES + X_BYTES;
   constexpr int DY_CPR = NB / 8;               // 16-byte chunks per dy row
-  constexpr int DY_IT = 256 * DY_CPR / 512;
-  constexpr int X_IT = kHwMaxHalo * 4 / 512;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n0 = bx * NB, c0 = by * 32, z = bz;
   const T* __restrict__ pdy = (const T*)a.dy;
   const T* __restrict__ px = (const T*)a.x;
   const int grp_rows = (a.R + 2) * a.pitch;
 
-  // ---- loader state
-  int xrel[X_IT], xlds[X_IT];      // x halo: pixel offset rel. to tile start; LDS byte offset | kind, or -1
+  const int t_begin = z * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  if (t_begin >= t_end) return;                 // (cannot happen: the launcher sizes the splits to the tiles)
+
+  if (wave >= 8) {
+    // ================================================================ loader waves
+    __builtin_amdgcn_s_setprio(3);
+    const int lw = wave - 8;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int DY_PIECES = DY_BYTES / 1024, DY_PW = DY_PIECES / 4;     // 1 KiB pieces of the dy tile, per loader wave
+    constexpr int RPP = 1024 / (NB * 2);                                  // dy rows per piece
+    constexpr int X_PW = kHwMaxHalo / 16 / 4;                             // x pieces per loader wave
+    // dy: lane L of piece p fills chunk position L % DY_CPR of row p*RPP + L / DY_CPR with the channel chunk the swizzle puts there
+    unsigned dy_voff[DY_PW];
 #pragma unroll
-  for (int i = 0; i < X_IT; ++i) {
-    const int id = t + 512 * i, hr = id >> 2, ch = id & 3;
-    xrel[i] = 0; xlds[i] = -1;
-    if (hr < a.HR) {
-      const int g = (int)fdiv((uint32_t)hr, a.d_grp), rem = hr - g * grp_rows;
-      const int hy = (int)fdiv((uint32_t)rem, a.d_pitch), hx = rem - hy * a.pitch;
-      if (hx <= a.W + 1) {
-        xrel[i] = g * a.R * a.W + (hy - 1) * a.W + (hx - 1);
-        const int kind = (hx == 0 || hx == a.W + 1) ? 1 : (hy == 0 ? 2 : (hy == a.R + 1 ? 3 : 0));
-        xlds[i] = xh_off(hr, ch) | kind;
+    for (int i = 0; i < DY_PW; ++i) {
+      const int row = (lw + 4 * i) * RPP + lane / DY_CPR, pos = lane % DY_CPR;
+      int c;
+      if (NB == 64) { const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1); c = (((pos >> 1) ^ f) << 1) | (pos & 1); }
+      else { c = (((pos >> 1) ^ ((row >> 3) & 1)) << 1) | (pos & 1); }
+      dy_voff[i] = n0 + c * 8 < a.Na ? (unsigned)(row * a.dy_cs + c * 8) * 2u : OOB;
+    }
+    // x halo: piece q covers halo rows [16q, 16q+16); offsets are bytes from (tile's first pixel - one image row)
+    const int l4 = lane >> 2, pos4 = lane & 3;
+    const unsigned m_grp = ((1u << 20) + grp_rows - 1) / grp_rows, m_pitch = ((1u << 20) + a.pitch - 1) / a.pitch;
+    const unsigned uW = (unsigned)a.W, uR1 = (unsigned)a.R + 1u, RW = (unsigned)(a.R * a.W);
+    const bool single = a.bands == 1;
+    const int npieces = (a.HR + 15) / 16;
+    unsigned x_voff[X_PW], topmask = 0, botmask = 0, skipmask = 0;
+#pragma unroll
+    for (int i = 0; i < X_PW; ++i) {
+      const int q = lw + 4 * i;
+      const unsigned hr = (unsigned)(q * 16 + l4);
+      const unsigned g = __umul24(hr, m_grp) >> 20, rem = hr - __umul24(g, (unsigned)grp_rows);
+      const unsigned hy = __umul24(rem, m_pitch) >> 20, hx = rem - __umul24(hy, (unsigned)a.pitch);
+      const bool top = hy == 0, bot = hy == uR1;
+      const bool on = (q < npieces) & (hr < (unsigned)a.HR) & (hx - 1u < uW) & !((top | bot) & single);
+      const int pix = (int)(__umul24(g, RW) + __umul24(hy, uW) + hx) - (int)(uW + 1u) + a.W;   // + one image row: never negative
+      const int c = (((pos4 >> 1) ^ (int)((hr >> 3) & 1u)) << 1) | (pos4 & 1);
+      x_voff[i] = on ? (unsigned)(__mul24(pix, a.x_cs) + c * 8) * 2u : OOB;
+      topmask |= (unsigned)(on & top) << i;
+      botmask |= (unsigned)(on & bot) << i;
+      const bool any = __builtin_amdgcn_ballot_w64(on) != 0;
+      skipmask |= (unsigned)(!any) << i;
+      if (!any && q < npieces) {        // an all-padding piece: zeroed once in both stages, no DMA ever writes it
+        *(u32x4_t*)(smem + DY_BYTES + q * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
+        *(u32x4_t*)(smem + STAGE + DY_BYTES + q * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
       }
     }
+    auto issue_tile = [&](int tile, int buf) {
+      char* D = smem + buf * STAGE + lw * 1024;
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<T*>(pdy + ((int64_t)tile * 256 * a.dy_cs + a.dy_co + n0)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < DY_PW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(D + i * 4096), 16, (int)dy_voff[i], 0, 0, 0);
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<T*>(px + ((int64_t)tile * 256 * a.x_cs + a.x_co + c0 - (int64_t)a.W * a.x_cs)), 0, 0x7fffffff, 0x00020000);
+      const int band = tile - (int)fdiv((uint32_t)tile, a.d_bands) * a.bands;
+      const unsigned zmask = single ? 0u : ((band == 0 ? topmask : 0u) | (band == a.bands - 1 ? botmask : 0u));
+      char* X = D + DY_BYTES;
+#pragma unroll
+      for (int i = 0; i < X_PW; ++i)
+        if (!((skipmask >> i) & 1))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(X + i * 4096), 16,
+                                                   (int)(((zmask >> i) & 1) ? OOB : x_voff[i]), 0, 0, 0);
+    };
+    issue_tile(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      if (tile + 1 < t_end) issue_tile(tile + 1, (tile + 1 - t_begin) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
   }
-  const int xchq = (t & 3) * 8;
-  // element offsets of the zero page relative to each operand's base pointer
-  const int64_t zoff_dy = ((intptr_t)a.zero - (intptr_t)a.dy) / 2, zoff_x = ((intptr_t)a.zero - (intptr_t)a.x) / 2;
-  const int dy_ch = t % DY_CPR, dy_row0 = t / DY_CPR;
-  const bool dy_ok = n0 + dy_ch * 8 < a.Na;
 
-  u32x4_t rdy[DY_IT], rx[X_IT];
-  auto load_tile = [&](int tile) {
-    const int64_t base = (int64_t)tile * 256;
-    const int band = tile - (int)fdiv((uint32_t)tile, a.d_bands) * a.bands;
-    const bool top0 = band == 0, bot0 = band == a.bands - 1;
-#pragma unroll
-    for (int i = 0; i < DY_IT; ++i) {
-      const int row = dy_row0 + i * (512 / DY_CPR);
-      // integer select of the offset from one base pointer (a select between two pointers makes
-      // the optimiser split the load into branches)
-      const int64_t off = dy_ok ? (base + row) * a.dy_cs + a.dy_co + n0 + dy_ch * 8 : zoff_dy;
-      rdy[i] = *(const u32x4_t*)(pdy + opaque_offset(off));
-    }
-    const int coff = a.x_co + c0 + xchq;
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i) {
-      const int kind = xlds[i] & 3;
-      const bool zero = xlds[i] < 0 || kind == 1 || (kind == 2 && top0) || (kind == 3 && bot0);
-      const int64_t off = zero ? zoff_x : (base + xrel[i]) * a.x_cs + coff;
-      rx[i] = *(const u32x4_t*)(px + opaque_offset(off));
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* D = smem + buf * STAGE;
-    char* X = D + DY_BYTES;
-#pragma unroll
-    for (int i = 0; i < DY_IT; ++i) *(u32x4_t*)(D + dy_off<NB>(dy_row0 + i * (512 / DY_CPR), dy_ch)) = rdy[i];
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i)
-      if (xlds[i] >= 0) *(u32x4_t*)(X + (xlds[i] & ~15)) = rx[i];
-  };
-
-  // ---- wave role and fragment addresses
+  // ---- wave role and fragment addresses (compute waves)
   const int combo = wave % COMBOS, pg = wave / COMBOS;
   const int ct = combo & 1, np = combo >> 1;
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
@@ -160,7 +188,8 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
     };
     auto read_b = [&](int k, int tp, int set) {
       const char* Sy = S + (tp / 3) * ty_bytes;
-      bfr[set] = tr_pair(Sy + b_addr[k][0][tp % 3], Sy + b_addr[k][1][tp % 3]);
+      const int flip = (RP && ((tp / 3) & 1)) ? 32 : 0;
+      bfr[set] = tr_pair(Sy + (b_addr[k][0][tp % 3] ^ flip), Sy + (b_addr[k][1][tp % 3] ^ flip));
     };
     read_a(0, 0);
     read_b(0, 0, 0);
@@ -185,20 +214,11 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
     }
   };
 
-  const int t_begin = z * a.tiles_per_split;
-  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
-  if (t_begin < t_end) {
-    load_tile(t_begin);
-    store_tile(0);
-    __syncthreads();
-    for (int tile = t_begin; tile < t_end; ++tile) {
-      const int s = tile - t_begin;
-      const bool more = tile + 1 < t_end;
-      if (more) load_tile(tile + 1);
-      compute(s & 1);
-      if (more) store_tile((s + 1) & 1);
-      __syncthreads();
-    }
+  __builtin_amdgcn_s_barrier();                 // the first tile has landed
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    compute((tile - t_begin) & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- combine the PG pixel groups of every accumulator block through LDS, upper half into
@@ -269,8 +289,8 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
 // workgroups of both share the CUs, so each layer needs only its share of pixel splits to fill
 // the chip and writes that many fewer partial slabs.  Workgroup ids run over layer 0 then layer 1,
 // n-block fastest.
-template <int NB>
-__global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradBatch p) {
+template <int NB, bool RP>
+__global__ __launch_bounds__(768) void hwgrad_kernel(const HwgradBatch p) {
   constexpr int STAGE = 256 * NB * 2 + kHwMaxHalo * 64;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int id = blockIdx.x;
@@ -280,13 +300,13 @@ __global__ __launch_bounds__(512, 2) void hwgrad_kernel(const HwgradBatch p) {
   const int gx = (a.Na + NB - 1) / NB, gy = a.Cb / 32;
   const int bz = id / (gx * gy), rem = id - bz * (gx * gy);
   const int by = rem / gx, bx = rem - by * gx;
-  hwgrad_body<NB>(a, bx, by, bz, smem);
+  hwgrad_body<NB, RP>(a, bx, by, bz, smem);
 }
 
 // Tiling with a 16-row-aligned halo pitch; false when the kernel does not apply.
 bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR) {
   if (!hconv_tiling(H, W, R, G, bands)) return false;
-  *pitch = (W + 2 + 15) / 16 * 16;
+  *pitch = W == 4 ? 8 : (W + 2 + 15) / 16 * 16;
   *HR = (*G) * (*R + 2) * (*pitch);
   return *HR <= kHwMaxHalo;
 }
@@ -307,12 +327,16 @@ int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const cha
   }
   p.wgs0 = hwgrad_wgs(p.layer[0], NB);
   const int total = p.wgs0 + (n > 1 ? hwgrad_wgs(p.layer[1], NB) : 0);
+  const bool rp = p.layer[0].pitch == 8;
+  for (int i = 0; i < n; ++i) MI_REQUIRE((p.layer[i].pitch == 8) == rp, "hwgrad: layers of one launch must share the halo pitch rule");
   if (NB == 64) {
     if (name) *name = "hwgrad_64x32x9";
-    hipLaunchKernelGGL((hwgrad_kernel<64>), dim3(total), dim3(512), 0, s, p);
+    if (rp) hipLaunchKernelGGL((hwgrad_kernel<64, true>), dim3(total), dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((hwgrad_kernel<64, false>), dim3(total), dim3(768), 0, s, p);
   } else {
     if (name) *name = "hwgrad_32x32x9";
-    hipLaunchKernelGGL((hwgrad_kernel<32>), dim3(total), dim3(512), 0, s, p);
+    if (rp) hipLaunchKernelGGL((hwgrad_kernel<32, true>), dim3(total), dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((hwgrad_kernel<32, false>), dim3(total), dim3(768), 0, s, p);
   }
   return check_hip(hipGetLastError(), "hwgrad launch");
 }
