@@ -135,7 +135,7 @@ int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kern
 // passed by value in the kernel arguments).
 //   conv3: dW (Cout,Cin,3,3), db from partials [z][Npad][9*Cp] / row sums [z][Npad]
 //   convT: dW (Cin,Cout,2,2), db from partials [z][Cp][4*Npad] / column sums [z][4*Npad] (Cp = padded Cin)
-enum FinKind { FIN_CONV3 = 0, FIN_CONVT = 1, FIN_CONV3_WIDE = 2 };
+enum FinKind { FIN_CONV3 = 0, FIN_CONVT = 1, FIN_CONV3_WIDE = 2, FIN_CONVT_WIDE = 3 };
 constexpr int kMaxFinJobs = 8;
 struct FinJob {
   int kind;

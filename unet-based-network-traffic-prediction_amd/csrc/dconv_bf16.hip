@@ -91,6 +91,13 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   __shared__ __attribute__((aligned(1024))) char smem[kDconvLds];
   const HconvArgs& a = d.h;
 
+  // every kernel argument is fetched HERE, in one batch: left to first use, the scalar loads came as
+  // dependent round trips spread over the prologue (about a microsecond before the first DMA)
+  pin_scalars(a.in, a.w, a.out, a.bias, a.mask, a.pool, a.zero, a.in_cs, a.in_co, a.out_cs, a.out_co, a.mask_cs, a.mask_co,
+              a.pool_cs, a.pool_co, a.Kp, a.Cp, a.n_real, a.relu, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles, a.nchunks,
+              a.d_bands.mul, a.d_bands.shift, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift,
+              d.na, d.a_slot, d.w_base, d.w_resident, d.pa, d.remap, d.gx, d.ny, d.d_ny.mul, d.d_ny.shift, d.d_gx.mul, d.d_gx.shift,
+              d.m_grp, d.m_pitch);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #ifdef MI_DCONV_DIAG
   const long long r_entry = (long long)__builtin_amdgcn_s_memrealtime();
@@ -109,12 +116,6 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   const int NA = d.na;
   const bool resident = d.w_resident != 0;
 
-  // every kernel argument is fetched HERE, in one batch: left to first use, the scalar loads came as
-  // eight dependent round trips spread over the prologue (about a microsecond before the first DMA)
-  pin_scalars(a.in, a.w, a.out, a.bias, a.mask, a.pool, a.zero, a.in_cs, a.in_co, a.out_cs, a.out_co, a.mask_cs, a.mask_co,
-              a.pool_cs, a.pool_co, a.Kp, a.Cp, a.n_real, a.relu, a.W, a.R, a.pitch, a.HR, a.bands, a.nchunks, d.a_slot, d.w_base,
-              d.pa, d.m_grp, d.m_pitch);
-
   if (wave >= 8) {
     // ================================================================ loader waves
 #ifdef MI_DCONV_DIAG
@@ -124,24 +125,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     const T* __restrict__ in = (const T*)a.in;
     const T* __restrict__ wp = (const T*)a.w;
     const int lw = wave - 8;
-    // weights first: their offsets are cheap, and the loads fly while the pixel-tile geometry is worked out
     const int l4 = lane >> 2, cpos = lane & 3;
-    unsigned w_voff[W_IT];            // byte offset of this lane's weight source for channel chunk 0
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int q = lw + 4 * i, row = q * 16 + l4;
-      const int tap = row / BN, n = row - tap * BN;
-      w_voff[i] = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
-    }
-    auto issue_w = [&](int chunk, int wslot) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + chunk * CK);
-      char* dst = smem + d.w_base + wslot * W_BYTES + lw * 1024;
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i)
-        if (lw + 4 * i < WP) dma16(rs, w_voff[i], dst + i * 4096);
-    };
-    if (resident) { for (int c = 0; c < a.nchunks; ++c) issue_w(c, c); }
-    else issue_w(0, 0);
     // Piece q of a pixel tile covers halo slots [16q, 16q+16): lane L fills chunk position L&3 of
     // slot 16q + (L>>2) with the channel chunk that the swizzle puts there.  Offsets are bytes from
     // (tile's first pixel - one image row): the top halo row of a band lies in the band above.
@@ -180,6 +164,21 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll 1
         for (int k = 0; k < NA; ++k) *(u32x4_t*)(smem + k * d.a_slot + (lw + 4 * i) * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
       }
+    // weights of the later stages (the compute waves, idle until the first data lands, issue chunk 0 / the resident chunks)
+    unsigned w_voff[W_IT];            // byte offset of this lane's weight source for channel chunk 0
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int q = lw + 4 * i, row = q * 16 + l4;
+      const int tap = row / BN, n = row - tap * BN;
+      w_voff[i] = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
+    }
+    auto issue_w = [&](int chunk, int wslot) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + chunk * CK);
+      char* dst = smem + d.w_base + wslot * W_BYTES + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i)
+        if (lw + 4 * i < WP) dma16(rs, w_voff[i], dst + i * 4096);
+    };
     auto issue_a = [&](int tile, int chunk, int slot) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + ((int64_t)tile * BM * a.in_cs + a.in_co + chunk * CK - margin));
       char* dst = smem + slot * d.a_slot + lw * 1024;
@@ -279,6 +278,24 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   }
   const int ty_bytes = a.pitch * 64;
 
+  // While the loaders work out the pixel-tile geometry, the compute waves (idle until the first data
+  // lands) put the first weights on their way: chunk 0, or every chunk when the weights stay resident.
+  {
+    constexpr int W_IT8 = (WP + 7) / 8;
+    const int l4 = lane >> 2, cpos = lane & 3;
+    const T* __restrict__ wp = (const T*)a.w;
+    const int nw = resident ? a.nchunks : 1;
+    for (int c = 0; c < nw; ++c) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + c * CK);
+#pragma unroll
+      for (int i = 0; i < W_IT8; ++i) {
+        const int q = wave + 8 * i, row = q * 16 + l4;
+        const int tap = row / BN, n = row - tap * BN;
+        const unsigned voff = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
+        if (q < WP) dma16(rs, voff, smem + d.w_base + c * W_BYTES + q * 1024);
+      }
+    }
+  }
   constexpr int CPL = 4 * TN;
   float biasv[CPL];
   {
@@ -389,6 +406,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #ifdef MI_DCONV_DIAG
   const long long r_ready = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the first weights (and its bias values)
   __builtin_amdgcn_s_barrier();     // the loaders' prologue: stage 0 has landed
 #ifdef MI_DCONV_DIAG
   const long long r_start = (long long)__builtin_amdgcn_s_memrealtime();

@@ -1095,32 +1095,32 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 // keeps 4 independent sums, so a layer with few outputs and many splits still spreads over
 // hundreds of workgroups with all its loads in flight at once, and a layer with few splits keeps
 // every thread busy.  The combination order is fixed, hence bitwise repeatable.
-__device__ __forceinline__ float sum_splits(const float* __restrict__ p, int64_t stride, int z0, int splits, int G) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+__device__ __forceinline__ f32x4_t sum_splits4(const float* __restrict__ p, int64_t stride, int z0, int splits, int G) {
+  // four consecutive columns per thread (16-byte loads), 8 loads in flight, two interleaved sums
+  f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   int z = z0;
-  // 16 loads in flight per thread (the partials of other workgroups come from HBM / remote L2)
-  for (; z + 15 * G < splits; z += 16 * G) {
-    float v[16];
+  for (; z + 7 * G < splits; z += 8 * G) {
+    f32x4_t v[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = p[(int64_t)(z + k * G) * stride];
+    for (int k = 0; k < 8; ++k) v[k] = *(const f32x4_t*)(p + (int64_t)(z + k * G) * stride);
 #pragma unroll
-    for (int k = 0; k < 16; k += 4) { a0 += v[k]; a1 += v[k + 1]; a2 += v[k + 2]; a3 += v[k + 3]; }
+    for (int k = 0; k < 8; k += 2) { a0 += v[k]; a1 += v[k + 1]; }
   }
-  for (; z + 3 * G < splits; z += 4 * G) {
-    const float v0 = p[(int64_t)z * stride], v1 = p[(int64_t)(z + G) * stride], v2 = p[(int64_t)(z + 2 * G) * stride],
-                v3 = p[(int64_t)(z + 3 * G) * stride];
-    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  for (; z + G < splits; z += 2 * G) {
+    const f32x4_t v0 = *(const f32x4_t*)(p + (int64_t)z * stride), v1 = *(const f32x4_t*)(p + (int64_t)(z + G) * stride);
+    a0 += v0; a1 += v1;
   }
-  for (; z < splits; z += G) a0 += p[(int64_t)z * stride];
-  return (a0 + a1) + (a2 + a3);
+  for (; z < splits; z += G) a0 += *(const f32x4_t*)(p + (int64_t)z * stride);
+  return a0 + a1;
 }
-__device__ __forceinline__ float combine_groups(float v, float* sh, int G, int cols) {
-  // sh: [G groups][cols columns]; returns the total in threads 0..cols-1
-  sh[threadIdx.x] = v;
+__device__ __forceinline__ f32x4_t combine_groups4(f32x4_t v, float* sh, int G, int cols) {
+  // sh: [G groups][cols quads]; returns the total in threads 0..cols-1
+  if (G == 1) return v;
+  ((f32x4_t*)sh)[threadIdx.x] = v;
   __syncthreads();
   const int o = threadIdx.x & (cols - 1);
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) s += sh[g * cols + o];
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < G; ++g) s += ((const f32x4_t*)sh)[g * cols + o];
   return s;
 }
 static inline int finalize_groups(int splits, int64_t outputs) {
@@ -1130,118 +1130,190 @@ static inline int finalize_groups(int splits, int64_t outputs) {
   return g;
 }
 // The three bodies below run as workgroup `vb` of `nb` of their job (one launch serves several layers).
-__device__ __forceinline__ void finalize_conv3_body(const FinJob& q, int vb, int nb, float* sh) {
-  const int Cp = q.Cp, Cout = q.Cout, G = q.G;
-  const int K = 9 * Cp;
-  const int split_pad = pad_ch(q.split);
-  const int64_t total = (int64_t)Cout * K + Cout;
-  const int cols = 256 / G;
-  const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
-  for (int64_t base = (int64_t)vb * cols; base < total; base += (int64_t)nb * cols) {
-    const int64_t i = base + o;
-    float v = 0.f;
-    int co = 0, k = 0;
-    const bool is_w = i < (int64_t)Cout * K, live = i < total;
-    if (live) {
-      if (is_w) {
-        co = (int)((uint32_t)i / (uint32_t)K); k = (int)((uint32_t)i - (uint32_t)co * (uint32_t)K);
-        v = sum_splits(q.part + (int64_t)co * K + k, (int64_t)q.Npad * K, zg, q.splits, G);
-      } else {
-        co = (int)(i - (int64_t)Cout * K);
-        if (q.sum) v = sum_splits(q.sum + co, q.Npad, zg, q.splits, G);
-      }
-    }
-    const float s = combine_groups(v, sh, G, cols);
-    if (zg == 0 && live) {
-      if (is_w) {
-        const int tap = k / Cp, pos = k % Cp;
-        const int ci = unpos(pos, q.Cin, q.split, split_pad);
-        if (ci >= 0) {
-          float* out = q.dW + ((int64_t)co * q.Cin + ci) * 9 + tap;
-          *out = q.alpha * s + (q.beta != 0.f ? q.beta * *out : 0.f);
-        }
-      } else if (q.db != nullptr) {
-        q.db[co] = q.alpha * s + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
-      }
-    }
-    __syncthreads();
-  }
-}
-// Transposed conv: partials [z][Cp][4*Npad], column sums [z][4*Npad]; Cp = padded input channels.
-__device__ __forceinline__ void finalize_convt_body(const FinJob& q, int vb, int nb, float* sh) {
-  const int Npad = q.Npad, Cin = q.Cin, Cout = q.Cout, G = q.G;
-  const int K = 4 * Npad;
-  const int64_t total = (int64_t)Cin * K + Cout;
-  const int cols = 256 / G;
-  const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
-  for (int64_t base = (int64_t)vb * cols; base < total; base += (int64_t)nb * cols) {
-    const int64_t i = base + o;
-    float v = 0.f;
-    int ci = 0, k = 0;
-    const bool is_w = i < (int64_t)Cin * K, live = i < total;
-    if (live) {
-      if (is_w) {
-        ci = (int)((uint32_t)i / (uint32_t)K); k = (int)((uint32_t)i - (uint32_t)ci * (uint32_t)K);
-        v = sum_splits(q.part + (int64_t)ci * K + k, (int64_t)q.Cp * K, zg, q.splits, G);
-      } else if (q.sum) {
-        const int co = (int)(i - (int64_t)Cin * K);
-        for (int g = 0; g < 4; ++g) v += sum_splits(q.sum + g * Npad + co, K, zg, q.splits, G);
-      }
-    }
-    const float s = combine_groups(v, sh, G, cols);
-    if (zg == 0 && live) {
-      if (is_w) {
-        const int g = k / Npad, co = k % Npad;
-        if (co < Cout) {
-          float* out = q.dW + ((int64_t)ci * Cout + co) * 4 + g;
-          *out = q.alpha * s + (q.beta != 0.f ? q.beta * *out : 0.f);
-        }
-      } else if (q.db != nullptr) {
-        const int co = (int)(i - (int64_t)Cin * K);
-        q.db[co] = q.alpha * s + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
-      }
-    }
-    __syncthreads();
-  }
-}
-// Few splits, large layers: one workgroup per (output channel, 64 packed input positions).  The
-// partial columns are read tap by tap (coalesced), transposed through LDS, and written as one
-// contiguous run of dW[co][ci][3][3].
-__device__ __forceinline__ void finalize_conv3_wide_body(const FinJob& q, int vb, float* sh) {
+// conv3: one workgroup per (output channel co, block of up to 64 packed input positions).  Its 9 x 64
+// partial columns are summed over the splits with 16-byte loads (the split range cut into G interleaved
+// groups when the block has fewer than 256 quads, combined through LDS in a fixed order), transposed
+// through LDS and written as ONE contiguous run of dW[co][ci][3][3]: the (tap, c) -> (c, tap) transposition
+// as scattered 4-byte stores 36 bytes apart was what the combine pass spent its time on.
+__device__ __forceinline__ void finalize_conv3_run_body(const FinJob& q, int vb, float* sh) {
   const int Cp = q.Cp, splits = q.splits;
   const int K = 9 * Cp;
   const int ny = (Cp + 63) / 64;
   const int co = vb / ny, pos0 = (vb - co * ny) * 64;
+  const int ncols = min(64, Cp - pos0), qpt = ncols / 4, nq = 9 * qpt;      // quads per tap, quads in all
+  int G = 256 / nq;
+  if (G > splits) G = splits;
+  if (G > 16) G = 16;
   const int split_pad = pad_ch(q.split);
-  for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
-    const int tap = idx >> 6, o = idx & 63;
-    float v = 0.f;
-    if (pos0 + o < Cp) {
-      const float* p = q.part + (int64_t)co * K + tap * Cp + pos0 + o;
-      for (int z = 0; z < splits; ++z) v += p[(int64_t)z * q.Npad * K];
+  f32x4_t* sh4 = (f32x4_t*)sh;                  // [G][nq] quads
+  float* so = sh + 4 * 256;                     // [9][64] sums
+  const int g = threadIdx.x / nq, qd = threadIdx.x - g * nq;
+  const int tap = qd / qpt, c4 = (qd - tap * qpt) * 4;
+  if (g < G) {
+    const f32x4_t v = sum_splits4(q.part + (int64_t)co * K + tap * Cp + pos0 + c4, (int64_t)q.Npad * K, g, splits, G);
+    if (G > 1) sh4[g * nq + qd] = v;
+    else { so[tap * 64 + c4] = v[0]; so[tap * 64 + c4 + 1] = v[1]; so[tap * 64 + c4 + 2] = v[2]; so[tap * 64 + c4 + 3] = v[3]; }
+  }
+  if (G > 1) {
+    __syncthreads();
+    if (g == 0) {
+      f32x4_t v = sh4[qd];
+      for (int k = 1; k < G; ++k) v += sh4[k * nq + qd];
+      so[tap * 64 + c4] = v[0]; so[tap * 64 + c4 + 1] = v[1]; so[tap * 64 + c4 + 2] = v[2]; so[tap * 64 + c4 + 3] = v[3];
     }
-    sh[idx] = v;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
-    const int cl = idx / 9, tap = idx - cl * 9;
-    if (pos0 + cl >= Cp) continue;
+  for (int idx = threadIdx.x; idx < 9 * ncols; idx += 256) {
+    const int cl = idx / 9, tp = idx - cl * 9;
     const int ci = unpos(pos0 + cl, q.Cin, q.split, split_pad);
     if (ci < 0) continue;
-    float* out = q.dW + ((int64_t)co * q.Cin + ci) * 9 + tap;
-    *out = q.alpha * sh[tap * 64 + cl] + (q.beta != 0.f ? q.beta * *out : 0.f);
+    float* out = q.dW + ((int64_t)co * q.Cin + ci) * 9 + tp;
+    *out = q.alpha * so[tp * 64 + cl] + (q.beta != 0.f ? q.beta * *out : 0.f);
   }
-  if (pos0 == 0 && threadIdx.x == 0 && q.db != nullptr) {
+  if (pos0 == 0 && threadIdx.x < 64 && q.db != nullptr) {
+    // bias gradient: lanes take the splits round-robin, then a fixed-order shuffle tree
     float v = 0.f;
     if (q.sum)
-      for (int z = 0; z < splits; ++z) v += q.sum[(int64_t)z * q.Npad + co];
+      for (int z = threadIdx.x; z < splits; z += 64) v += q.sum[(int64_t)z * q.Npad + co];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) q.db[co] = q.alpha * v + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
+  }
+}
+// Transposed conv: partials [z][Cp][4*Npad], column sums [z][4*Npad]; Cp = padded input channels.  One workgroup
+// per (input channel ci, block of 64 output channels): 4 x 64 columns in, one contiguous run of dW[ci][co][2][2] out.
+__device__ __forceinline__ void finalize_convt_run_body(const FinJob& q, int vb, float* sh) {
+  const int Npad = q.Npad, Cout = q.Cout, splits = q.splits;
+  const int K = 4 * Npad;
+  const int ny = (Npad + 63) / 64;
+  const int ci = vb / ny, co0 = (vb - ci * ny) * 64;
+  const int ncols = min(64, Npad - co0), qpt = ncols / 4, nq = 4 * qpt;
+  int G = 256 / nq;
+  if (G > splits) G = splits;
+  if (G > 16) G = 16;
+  f32x4_t* sh4 = (f32x4_t*)sh;
+  float* so = sh + 4 * 256;                     // [4][64]
+  const int g = threadIdx.x / nq, qd = threadIdx.x - g * nq;
+  const int tg = qd / qpt, c4 = (qd - tg * qpt) * 4;
+  if (g < G) {
+    const f32x4_t v = sum_splits4(q.part + (int64_t)ci * K + tg * Npad + co0 + c4, (int64_t)q.Cp * K, g, splits, G);
+    if (G > 1) sh4[g * nq + qd] = v;
+    else { so[tg * 64 + c4] = v[0]; so[tg * 64 + c4 + 1] = v[1]; so[tg * 64 + c4 + 2] = v[2]; so[tg * 64 + c4 + 3] = v[3]; }
+  }
+  if (G > 1) {
+    __syncthreads();
+    if (g == 0) {
+      f32x4_t v = sh4[qd];
+      for (int k = 1; k < G; ++k) v += sh4[k * nq + qd];
+      so[tg * 64 + c4] = v[0]; so[tg * 64 + c4 + 1] = v[1]; so[tg * 64 + c4 + 2] = v[2]; so[tg * 64 + c4 + 3] = v[3];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 4 * ncols; idx += 256) {
+    const int cl = idx >> 2, tp = idx & 3;
+    if (co0 + cl >= Cout) continue;
+    float* out = q.dW + ((int64_t)ci * Cout + co0 + cl) * 4 + tp;
+    *out = q.alpha * so[tp * 64 + cl] + (q.beta != 0.f ? q.beta * *out : 0.f);
+  }
+  if (ci == 0 && q.db != nullptr && threadIdx.x < ncols && co0 + threadIdx.x < Cout) {
+    const int co = co0 + threadIdx.x;
+    float v = 0.f;
+    if (q.sum)
+      for (int z = 0; z < splits; ++z)
+        for (int tp = 0; tp < 4; ++tp) v += q.sum[(int64_t)z * K + tp * Npad + co];
     q.db[co] = q.alpha * v + (q.beta != 0.f ? q.beta * q.db[co] : 0.f);
+  }
+}
+// Layers with MANY splits and few outputs (the shallow levels: 32-64 channels, up to a few hundred slabs):
+// work items are quads of four consecutive partial columns, 256/G quads per workgroup, the split range cut
+// into G interleaved groups -- hundreds of workgroups with all loads in flight; the scattered 4-byte stores
+// do not matter at these output sizes.
+__device__ __forceinline__ void finalize_conv3_body(const FinJob& q, int vb, int nb, float* sh) {
+  const int Cp = q.Cp, Cout = q.Cout, G = q.G;
+  const int K = 9 * Cp;
+  const int split_pad = pad_ch(q.split);
+  const int64_t wquads = (int64_t)Cout * K / 4, total = wquads + (Cout + 3) / 4;
+  const int cols = 256 / G;
+  const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
+  for (int64_t base = (int64_t)vb * cols; base < total; base += (int64_t)nb * cols) {
+    const int64_t i4 = base + o;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    int co = 0, k = 0;
+    const bool is_w = i4 < wquads, live = i4 < total;
+    if (live) {
+      if (is_w) {
+        const uint32_t i = (uint32_t)i4 * 4u;
+        co = (int)(i / (uint32_t)K); k = (int)(i - (uint32_t)co * (uint32_t)K);
+        v = sum_splits4(q.part + (int64_t)co * K + k, (int64_t)q.Npad * K, zg, q.splits, G);
+      } else {
+        co = (int)(i4 - wquads) * 4;
+        if (q.sum) v = sum_splits4(q.sum + co, q.Npad, zg, q.splits, G);
+      }
+    }
+    const f32x4_t s = combine_groups4(v, sh, G, cols);
+    if (zg == 0 && live) {
+      if (is_w) {
+        const int tap = k / Cp, pos = k - tap * Cp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ci = unpos(pos + e, q.Cin, q.split, split_pad);
+          if (ci >= 0) {
+            float* out = q.dW + ((int64_t)co * q.Cin + ci) * 9 + tap;
+            *out = q.alpha * s[e] + (q.beta != 0.f ? q.beta * *out : 0.f);
+          }
+        }
+      } else if (q.db != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < Cout) q.db[co + e] = q.alpha * s[e] + (q.beta != 0.f ? q.beta * q.db[co + e] : 0.f);
+      }
+    }
+    if (G > 1) __syncthreads();
+  }
+}
+__device__ __forceinline__ void finalize_convt_body(const FinJob& q, int vb, int nb, float* sh) {
+  const int Npad = q.Npad, Cin = q.Cin, Cout = q.Cout, G = q.G;
+  const int K = 4 * Npad;
+  const int64_t wquads = (int64_t)Cin * K / 4, total = wquads + (Cout + 3) / 4;
+  const int cols = 256 / G;
+  const int o = threadIdx.x & (cols - 1), zg = threadIdx.x / cols;
+  for (int64_t base = (int64_t)vb * cols; base < total; base += (int64_t)nb * cols) {
+    const int64_t i4 = base + o;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    int ci = 0, k = 0;
+    const bool is_w = i4 < wquads, live = i4 < total;
+    const int co4 = (int)(i4 - wquads) * 4;
+    if (live) {
+      if (is_w) {
+        const uint32_t i = (uint32_t)i4 * 4u;
+        ci = (int)(i / (uint32_t)K); k = (int)(i - (uint32_t)ci * (uint32_t)K);
+        v = sum_splits4(q.part + (int64_t)ci * K + k, (int64_t)q.Cp * K, zg, q.splits, G);
+      } else if (q.sum) {
+        for (int g = 0; g < 4; ++g) v += sum_splits4(q.sum + g * Npad + co4, K, zg, q.splits, G);
+      }
+    }
+    const f32x4_t s = combine_groups4(v, sh, G, cols);
+    if (zg == 0 && live) {
+      if (is_w) {
+        const int g = k / Npad, co = k - g * Npad;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < Cout) {
+            float* out = q.dW + ((int64_t)ci * Cout + co + e) * 4 + g;
+            *out = q.alpha * s[e] + (q.beta != 0.f ? q.beta * *out : 0.f);
+          }
+      } else if (q.db != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co4 + e < Cout) q.db[co4 + e] = q.alpha * s[e] + (q.beta != 0.f ? q.beta * q.db[co4 + e] : 0.f);
+      }
+    }
+    if (G > 1) __syncthreads();
   }
 }
 // One launch for all the layers of a backward segment: a chain of small dependent launches costs
 // more in dispatch gaps than the sums themselves.
 __global__ __launch_bounds__(256) void finalize_multi_kernel(const FinJobs J) {
-  __shared__ float sh[9 * 64];
+  __shared__ __attribute__((aligned(16))) float sh[4 * 256 + 9 * 64];
   int j = 0;
   while (j + 1 < J.n && (int)blockIdx.x >= J.job[j].block_end) ++j;
   const FinJob& q = J.job[j];
@@ -1249,7 +1321,8 @@ __global__ __launch_bounds__(256) void finalize_multi_kernel(const FinJobs J) {
   const int vb = (int)blockIdx.x - first, nb = q.block_end - first;
   if (q.kind == FIN_CONV3) finalize_conv3_body(q, vb, nb, sh);
   else if (q.kind == FIN_CONVT) finalize_convt_body(q, vb, nb, sh);
-  else finalize_conv3_wide_body(q, vb, sh);
+  else if (q.kind == FIN_CONV3_WIDE) finalize_conv3_run_body(q, vb, sh);
+  else finalize_convt_run_body(q, vb, sh);
 }
 static int fin_push(FinJobs& J, FinJob q, int blocks) {
   if (J.n >= kMaxFinJobs) return fail(MI_EINVAL, "finalize: too many jobs in one launch");
@@ -1263,13 +1336,13 @@ int fin_jobs_add_conv3(FinJobs& J, const float* part, const float* rowsum, int s
   FinJob q{};
   q.part = part; q.sum = rowsum; q.splits = splits; q.Npad = Npad; q.Cp = Cp; q.Cout = Cout; q.Cin = Cin; q.split = split;
   q.dW = dW; q.db = db; q.alpha = alpha; q.beta = beta;
-  if (splits <= 8 && (int64_t)Cout * Cp >= 64 * 256) {
+  if (splits <= 16) {      // few slabs: one workgroup per contiguous output run
     q.kind = FIN_CONV3_WIDE; q.G = 1;
     return fin_push(J, q, Cout * ((Cp + 63) / 64));
   }
-  const int64_t total = (int64_t)Cout * 9 * Cp + Cout;
-  q.kind = FIN_CONV3; q.G = finalize_groups(splits, total);
-  return fin_push(J, q, grid_for(total, 256 / q.G, 8192));
+  const int64_t quads = (int64_t)Cout * 9 * Cp / 4 + (Cout + 3) / 4;
+  q.kind = FIN_CONV3; q.G = finalize_groups(splits, quads);
+  return fin_push(J, q, grid_for(quads, 256 / q.G, 8192));
 }
 int fin_jobs_add_convt(FinJobs& J, const float* part, const float* colsum, int splits, int Cp_in, int Npad, int Cin,
                        int Cout, float* dW, float* db, float alpha, float beta) {
@@ -1278,8 +1351,13 @@ int fin_jobs_add_convt(FinJobs& J, const float* part, const float* colsum, int s
   FinJob q{};
   q.kind = FIN_CONVT; q.part = part; q.sum = colsum; q.splits = splits; q.Npad = Npad; q.Cp = Cp_in; q.Cout = Cout; q.Cin = Cin;
   q.dW = dW; q.db = db; q.alpha = alpha; q.beta = beta;
-  q.G = finalize_groups(splits, total);
-  return fin_push(J, q, grid_for(total, 256 / q.G, 8192));
+  if (splits <= 16) {
+    q.kind = FIN_CONVT_WIDE; q.G = 1;
+    return fin_push(J, q, Cin * ((Npad + 63) / 64));
+  }
+  const int64_t quads = (int64_t)Cin * Npad + (Cout + 3) / 4;
+  q.G = finalize_groups(splits, quads);
+  return fin_push(J, q, grid_for(quads, 256 / q.G, 8192));
 }
 int launch_finalize_multi(const FinJobs& J, hipStream_t s) {
   if (J.n == 0) return MI_OK;
