@@ -78,10 +78,13 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int cs, int co, f
     dst[((int64_t)b * C + c) * HW + r] = to_f(src[(int64_t)p * cs + co + c]);
   }
 }
+int launch_nchw_to_nhwc_vec(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype, hipStream_t s);
 int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype,
                         hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
   const int Cp = pad_ch(C);
+  if ((H * W) % 4 == 0 && ((uintptr_t)src & 15) == 0 && npix * (Cp / 4) < (1ll << 31))
+    return launch_nchw_to_nhwc_vec(src, dst, cs, co, B, C, H, W, dtype, s);
   const int64_t total = npix * ((Cp + 31) / 32);
   MI_REQUIRE(total < (1ll << 31), "nchw_to_nhwc: tensor too large");
   const int grid = grid_for(total, 256, 256 * 16);
@@ -410,6 +413,53 @@ template <> struct Vec16<__bf16> {
     *(bf16x8_t*)p = t;
   }
 };
+// The same conversion for plane sizes that are multiples of 4 (every benchmark shape): one thread per
+// (4 consecutive pixels, 16-byte channel group).  It reads its N channels as N float4s -- 16-byte loads,
+// lanes of a group walking consecutive pixel quads of a channel plane -- and writes each pixel's N channels
+// as one 16-byte store, the lanes of one pixel covering a contiguous run of its row.  Index math is 32-bit.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_vec_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
+                                                               uint32_t nquads, int C, int Cp, uint32_t HW, FastDiv dG, FastDiv dHW4) {
+  constexpr int N = Vec16<T>::N;
+  const uint32_t G = (uint32_t)Cp / N;
+  const uint32_t total = nquads * G;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t pq = fdiv(i, dG), cg = i - pq * G;
+    const uint32_t b = fdiv(pq, dHW4), r = (pq - b * (HW / 4)) * 4;       // image, first pixel of the quad inside its plane
+    const int c0 = (int)cg * N;
+    f32x4_t v[N];
+    if (c0 < C) {
+      const float* sp = src + ((int64_t)b * C + c0) * HW + r;
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = *(const f32x4_t*)(sp + (int64_t)(c0 + k < C ? k : 0) * HW);
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (c0 + k >= C) v[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    T* dp = dst + ((int64_t)b * HW + r) * cs + co + c0;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float row[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) row[k] = v[k][px];
+      Vec16<T>::store(dp + (int64_t)px * cs, row);
+    }
+  }
+}
+int launch_nchw_to_nhwc_vec(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype, hipStream_t s) {
+  const int Cp = pad_ch(C);
+  const uint32_t HW = (uint32_t)(H * W), nquads = (uint32_t)((int64_t)B * HW / 4);
+  const int G = Cp / (dtype == MI_BF16 ? 8 : 4);
+  const int grid = grid_for((int64_t)nquads * G, 256, 256 * 32);
+  if (dtype == MI_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, nquads, C, Cp, HW, make_fastdiv(G), make_fastdiv(HW / 4));
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, nquads, C, Cp, HW, make_fastdiv(G), make_fastdiv(HW / 4));
+  return check_hip(hipGetLastError(), "nchw_to_nhwc");
+}
 template <typename T, typename I>
 __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xcs, int xco, T* __restrict__ y, int ycs,
                                     int yco, int B, int H, int W, int Cp) {
@@ -447,14 +497,15 @@ template <typename T, typename I, bool EVEN, bool SKIP>
 __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dyp,
                                     int pcs, int pco, const T* __restrict__ dskip, int scs, int sco,
                                     T* __restrict__ dx, int dcs, int dco, int B, int H, int W, int Cp,
-                                    int relu_mask) {
+                                    int relu_mask, FastDiv dG, FastDiv dWc, FastDiv dHc) {
   constexpr int N = Vec16<T>::N;
   const I Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2, G = Cp / N;
   const I total = (I)B * Hc * Wc * G;
   for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (I)gridDim.x * blockDim.x) {
-    const I wdx = i / G, g = i - wdx * G;
-    const I t1 = wdx / Wc, ox = wdx - t1 * Wc;
-    const I b = t1 / Hc, oy = t1 - b * Hc;
+    I wdx, t1, b;
+    if (sizeof(I) == 4) { wdx = (I)fdiv((uint32_t)i, dG); t1 = (I)fdiv((uint32_t)wdx, dWc); b = (I)fdiv((uint32_t)t1, dHc); }
+    else { wdx = i / G; t1 = wdx / Wc; b = t1 / Hc; }
+    const I g = i - wdx * G, ox = wdx - t1 * Wc, oy = t1 - b * Hc;
     const bool pooled = EVEN || (oy < Ho && ox < Wo);  // window produced a pooled output
     float xv[4][N], gv[4][N];
     bool inb[4];
@@ -524,7 +575,8 @@ static void maxpool2_bwd_dispatch2(bool even, int grid, hipStream_t s, const voi
                                    int B, int H, int W, int Cp, int relu_mask) {
 #define POOL_BWD(EV, SK)                                                                                               \
   hipLaunchKernelGGL((maxpool2_bwd_kernel<T, I, EV, SK>), dim3(grid), dim3(256), 0, s, (const T*)x, xcs, xco, (const T*)dyp, \
-                     pcs, pco, (const T*)dskip, scs, sco, (T*)dx, dcs, dco, B, H, W, Cp, relu_mask)
+                     pcs, pco, (const T*)dskip, scs, sco, (T*)dx, dcs, dco, B, H, W, Cp, relu_mask, \
+                     make_fastdiv(Cp / Vec16<T>::N), make_fastdiv((W + 1) / 2), make_fastdiv((H + 1) / 2))
   if (even && dskip) POOL_BWD(true, true);
   else if (even) POOL_BWD(true, false);
   else if (dskip) POOL_BWD(false, true);
@@ -579,6 +631,44 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
     }
   }
 }
+// 32-channel inputs (every U-Net here): CP/N lanes share a pixel, each loading ONE 16-byte piece of its row, so a
+// wave's load instruction covers a contiguous kilobyte instead of 64 rows at a 64-byte stride; the partial dot
+// products meet through lane shuffles inside the pixel's lane group.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_quad_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ pred, uint32_t npix, FastDiv dHW, int Cin,
+                                                             int Cout) {
+  constexpr int CP = 32, N = Vec16<T>::N, LPP = CP / N;
+  __shared__ float sw[kHeadMaxCout * CP + kHeadMaxCout];
+  for (int i = threadIdx.x; i < Cout * CP; i += blockDim.x) {
+    const int co = i / CP, c = i % CP;
+    sw[i] = c < Cin ? w[co * Cin + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sw[Cout * CP + i] = bias[i];
+  __syncthreads();
+  const int cg = threadIdx.x % LPP;
+  const uint32_t HW = dHW.d, stride = gridDim.x * (256 / LPP);
+  for (uint32_t p0 = blockIdx.x * (256 / LPP) + threadIdx.x / LPP; p0 < npix; p0 += 2 * stride) {
+    // two pixels per trip: both rows in flight together (the second clamped to the last pixel, its result unused)
+    const uint32_t p1 = p0 + stride, q1 = p1 < npix ? p1 : npix - 1;
+    float v0[N], v1[N];
+    Vec16<T>::load(x + (int64_t)p0 * xcs + xco + cg * N, v0);
+    Vec16<T>::load(x + (int64_t)q1 * xcs + xco + cg * N, v1);
+    const uint32_t b0 = fdiv(p0, dHW), r0 = p0 - b0 * HW, b1 = fdiv(q1, dHW), r1 = q1 - b1 * HW;
+    for (int co = 0; co < Cout; ++co) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < N; ++q) { const float wv = sw[co * CP + cg * N + q]; a0 = fmaf(v0[q], wv, a0); a1 = fmaf(v1[q], wv, a1); }
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+      if (cg == 0) {
+        pred[((int64_t)b0 * Cout + co) * HW + r0] = a0 + sw[Cout * CP + co];
+        if (p1 < npix) pred[((int64_t)b1 * Cout + co) * HW + r1] = a1 + sw[Cout * CP + co];
+      }
+    }
+  }
+}
 int launch_head_fwd(const void* x, int xcs, int xco, const float* w, const float* bias, float* pred, int B, int H,
                     int W, int Cin, int Cout, int dtype, hipStream_t s) {
   MI_REQUIRE(pad_ch(Cin) <= kHeadMaxCin && Cout <= kHeadMaxCout, "head: Cin <= 64 and Cout <= 16 supported");
@@ -586,6 +676,15 @@ int launch_head_fwd(const void* x, int xcs, int xco, const float* w, const float
   MI_REQUIRE(npix < (1ll << 31), "head: pixel count out of range");
   const int grid = grid_for(npix, 256, 256 * 16);
   const int Cp = pad_ch(Cin);
+  if (Cp == 32) {
+    const int lpp = dtype == MI_BF16 ? 4 : 8;
+    const int g2 = grid_for(npix * lpp / 2, 256, 256 * 16);
+    if (dtype == MI_BF16)
+      hipLaunchKernelGGL(head_fwd_quad_kernel<__bf16>, dim3(g2), dim3(256), 0, s, (const __bf16*)x, xcs, xco, w, bias, pred, (uint32_t)npix, make_fastdiv(H * W), Cin, Cout);
+    else
+      hipLaunchKernelGGL(head_fwd_quad_kernel<float>, dim3(g2), dim3(256), 0, s, (const float*)x, xcs, xco, w, bias, pred, (uint32_t)npix, make_fastdiv(H * W), Cin, Cout);
+    return check_hip(hipGetLastError(), "head_fwd");
+  }
 #define HEAD_FWD(TT, CPV) \
   hipLaunchKernelGGL((head_fwd_kernel<TT, CPV>), dim3(grid), dim3(256), 0, s, (const TT*)x, xcs, xco, w, bias, pred, npix, H * W, Cin, Cout)
   if (dtype == MI_BF16) {
@@ -736,6 +835,86 @@ __global__ __launch_bounds__(256) void head_bwd_small_kernel(const T* __restrict
   for (int i = threadIdx.x; i < COUT * CP + COUT; i += 256)
     part[(int64_t)blockIdx.x * (COUT * CP + COUT) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
+// Head backward for one or two output channels on 32-channel inputs, CP/N lanes per pixel (see head_fwd_quad_kernel):
+// every lane owns one 16-byte piece of its pixels' rows -- dx piece out, dW piece accumulated in registers across a
+// grid-stride loop -- and the lanes owning the same piece meet once, at the end.  Partials: [block][COUT*CP + COUT].
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void head_bwd_quad_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                             const float* __restrict__ w, const float* __restrict__ dpred,
+                                                             T* __restrict__ dx, int dcs, int dco, float* __restrict__ part,
+                                                             uint32_t npix, FastDiv dHW, int Cin, int relu_mask) {
+  constexpr int CP = 32, N = Vec16<T>::N, LPP = CP / N;
+  __shared__ float red[4][COUT * CP + COUT];
+  const int cg = threadIdx.x % LPP;
+  float wr[COUT][N];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int q = 0; q < N; ++q) { const int c = cg * N + q; wr[co][q] = c < Cin ? w[co * Cin + (c < Cin ? c : 0)] : 0.f; }
+  float acc[COUT][N], accb[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    accb[co] = 0.f;
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[co][q] = 0.f;
+  }
+  const uint32_t HW = dHW.d, stride = gridDim.x * (256 / LPP);
+  constexpr int U = 4;                     // pixels in flight per lane
+  for (uint32_t pb = blockIdx.x * (256 / LPP) + threadIdx.x / LPP; pb < npix; pb += U * stride) {
+    float xv[U][N], g[U][COUT];
+    uint32_t pp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = pb + u * stride;
+      pp[u] = p < npix ? p : npix - 1;     // clamped: loaded, contributes nothing, not stored
+      Vec16<T>::load(x + (int64_t)pp[u] * xcs + xco + cg * N, xv[u]);
+      const uint32_t b = fdiv(pp[u], dHW), r = pp[u] - b * HW;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) g[u][co] = dpred[((int64_t)b * COUT + co) * HW + r];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = pb + u * stride < npix;
+      float d[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) d[q] = 0.f;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        const float gv = live ? g[u][co] : 0.f;
+        if (cg == 0) accb[co] += gv;
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          d[q] = fmaf(gv, wr[co][q], d[q]);
+          acc[co][q] = fmaf(gv, xv[u][q], acc[co][q]);
+        }
+      }
+      if (relu_mask) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) d[q] = xv[u][q] > 0.f ? d[q] : 0.f;
+      }
+      if (live) Vec16<T>::store(dx + (int64_t)pp[u] * dcs + dco + cg * N, d);
+    }
+  }
+  // lanes that own the same 16-byte piece (lane % LPP) meet: xor offsets LPP .. 32, a fixed order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      float v = acc[co][q];
+#pragma unroll
+      for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane < LPP) red[wave][co * CP + lane * N + q] = v;
+    }
+    float vb = accb[co];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) vb += __shfl_xor(vb, o, 64);
+    if (lane == 0) red[wave][COUT * CP + co] = vb;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < COUT * CP + COUT; i += 256)
+    part[(int64_t)blockIdx.x * (COUT * CP + COUT) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
 // Head backward for 3..16 output channels on a 32-channel input (the multi-step prediction head):
 // four threads share a pixel, each owning 8 of its input channels, so the dW rows a thread keeps
 // in registers are COUTP x 8 instead of COUTP x 32 and the loads stay 16 bytes wide.  Partials have
@@ -848,11 +1027,12 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
   const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
   const int nblocks = (int)(ntiles < kHeadBlocks ? ntiles : kHeadBlocks);
   if (Cout <= 2 && Cp == 32) {
-    int nb = (int)((npix + 255) / 256);
+    int nb = (int)((npix * (dtype == MI_BF16 ? 4 : 8) / 4 + 255) / 256);      // four pixels in flight per lane
     if (nb > kHeadBlocks) nb = kHeadBlocks;
+    if (nb < 1) nb = 1;
 #define HEAD_SMALL(TT, CO, CPV)                                                                                   \
-    hipLaunchKernelGGL((head_bwd_small_kernel<TT, CO, CPV>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred, \
-                       (TT*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, relu_mask)
+    hipLaunchKernelGGL((head_bwd_quad_kernel<TT, CO>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred, \
+                       (TT*)dx, dcs, dco, (float*)ws, (uint32_t)npix, make_fastdiv(H * W), Cin, relu_mask)
     if (dtype == MI_BF16) {
       if (Cout == 1) HEAD_SMALL(__bf16, 1, 32); else HEAD_SMALL(__bf16, 2, 32);
     } else {
