@@ -28,6 +28,8 @@ int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_dconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
+bool sconv_applies(const IgemmArgs& a);
+int launch_sconv_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
 bool tconv_eligible(const IgemmArgs& a);
@@ -95,6 +97,8 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
   MI_REQUIRE(a.epi == E_PLAIN || a.bias != nullptr, "igemm: bias required by this epilogue");
   MI_REQUIRE(a.epi != E_SHUFFLE_BIAS || (a.shufC % 16 == 0 && a.N == 4 * a.shufC), "igemm: bad shuffle width");
   MI_REQUIRE(a.in_co + a.Cin <= a.in_cs, "igemm: input channel range exceeds the view stride");
+  // 3x3 layers of so few pixels that a pixel-tiled kernel would leave most CUs idle: K-split kernel
+  if (dtype == MI_BF16 && sconv_applies(a)) return launch_sconv_bf16(a, s, name);
   // 3x3 stride-1 convolutions whose images tile evenly into 256-pixel blocks take the halo-tile
   // kernel (one LDS halo tile serves all 9 taps); everything else the generic gather kernel.
   if (a.mode == G_3x3 && a.epi != E_SHUFFLE_BIAS && a.M % 256 == 0 && a.Hi == a.Ho && a.Wi == a.Wo) {

@@ -78,6 +78,8 @@ struct IgemmArgs {
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;  // optional: out *= (mask > 0)
   void* pool; int pool_cs, pool_co;        // optional (3x3 forward only): also write the 2x2 max-pool of the output
+  void* kscratch; size_t kscratch_bytes;   // optional: zero-initialised scratch that lets a layer of few pixels split K across workgroups
+                                           // (the kernel leaves its counters at zero; concurrent launches must not share it)
   int epi;
   int shufC;                             // E_SHUFFLE_BIAS: N = 4*shufC
   int M;
@@ -136,6 +138,9 @@ int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kern
 //   conv3: dW (Cout,Cin,3,3), db from partials [z][Npad][9*Cp] / row sums [z][Npad]
 //   convT: dW (Cin,Cout,2,2), db from partials [z][Cp][4*Npad] / column sums [z][4*Npad] (Cp = padded Cin)
 enum FinKind { FIN_CONV3 = 0, FIN_CONVT = 1, FIN_CONV3_WIDE = 2, FIN_CONVT_WIDE = 3 };
+// scratch a caller may lend to the few-pixel 3x3 kernel: arrival counters (zeroed once), then partial tiles
+constexpr size_t kKsplitCounterBytes = 1024;
+constexpr size_t kKsplitBytes = kKsplitCounterBytes + (2u << 20);
 constexpr int kMaxFinJobs = 8;
 struct FinJob {
   int kind;

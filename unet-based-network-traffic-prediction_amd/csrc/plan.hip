@@ -82,6 +82,7 @@ struct mi_unet_plan {
   std::vector<Segment> segs;
   int64_t flat_elems;
   size_t ws_bytes, scratch_off, scratch_bytes;
+  size_t ksplit_off = 0, ksplit_bytes = 0;   // scratch of the few-pixel conv kernel (arrival counters first)
   bool forward_done;
   bool profile;
   std::vector<ProfRec> prof;
@@ -316,6 +317,7 @@ int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, con
   IgemmArgs a = conv3x3_fwd_args(x.p, x.cs, x.co, r.ws + l.wf_off, r.Bv(l), y.p, y.cs, y.co, B, H, W, l.cin, l.split,
                                  l.cout, 1);
   if (pool) { a.pool = pool->p; a.pool_cs = pool->cs; a.pool_co = pool->co; }
+  if (r.P->ksplit_bytes) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
   return rc;
@@ -327,6 +329,7 @@ int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, in
   const char* k = nullptr;
   IgemmArgs a = conv3x3_dgrad_args(dy.p, dy.cs, dy.co, r.ws + l.wb_off, dx.p, dx.cs, dx.co, mask ? mask->p : nullptr,
                                    mask ? mask->cs : 0, mask ? mask->co : 0, B, H, W, l.cin, l.split, l.cout);
+  if (r.P->ksplit_bytes) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
   return rc;
@@ -605,6 +608,18 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   P->scratch_off = cur; P->scratch_bytes = align_up(head_ws_bytes(d.features[0], d.out_channels), 256);
   cur += P->scratch_bytes;
   {
+    // scratch for splitting K across workgroups: only when some level is small enough in pixels
+    // and wide enough in channels (K of 4096 and up) for the few-pixel conv kernel to use it
+    bool any = false;
+    for (int l = 0; l <= L && d.dtype == MI_BF16; ++l) {
+      const int f = l < L ? d.features[l] : 2 * fb;
+      const int64_t M = (int64_t)B * P->h[l] * P->w[l];
+      const int kmax = 9 * (l < L ? 2 * pad_ch(f) : pad_ch(f));
+      if (M * pad_ch(l < L ? f : f / 2) < (64 << 13) && kmax >= 4096) any = true;
+    }
+    if (any) { P->ksplit_off = cur; P->ksplit_bytes = kKsplitBytes; cur += kKsplitBytes; }
+  }
+  {
     int lvl_h, lvl_w;
     for (auto& l : P->layers) {
       // spatial size of the layer's OUTPUT grid for conv3 / INPUT grid for convT
@@ -753,6 +768,9 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     const bool train = (flags & MI_FWD_TRAIN) != 0;
     Scope sc(P, r.s, "pack_weights", 0, 0);
     sc.kernel("pack");
+    // a workspace that needs its weights packed may be new: the arrival counters of the few-pixel
+    // conv kernel start at zero (the kernel itself leaves them there)
+    if (P->ksplit_bytes) RUN(check_hip(hipMemsetAsync(r.ws + P->ksplit_off, 0, kKsplitCounterBytes, r.s), "zero the K-split counters"));
     PackJobs J;
     J.n = 0;
     for (const auto& l : P->layers) {
