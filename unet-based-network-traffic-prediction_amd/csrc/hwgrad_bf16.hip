@@ -27,15 +27,28 @@ namespace mi {
 
 constexpr int kHwMaxHalo = 768;   // halo rows (pitch-padded) the LDS buffer holds: 16 images of 4x4 at pitch 8
 
-// dy tile: [256][NB] bf16.  NB = 64 -> 128-byte rows (32-byte column group ^ row bits 1,3);
-// NB = 32 -> 64-byte rows (32-byte column group ^ row bit 3).
-template <int NB> __device__ __forceinline__ int dy_off(int r, int q /*16-byte chunk*/);
-template <> __device__ __forceinline__ int dy_off<64>(int r, int q) { return tile_off<__bf16>(r, q); }
-template <> __device__ __forceinline__ int dy_off<32>(int r, int q) {
-  return r * 64 + (((((q >> 1) ^ ((r >> 3) & 1)) << 1) | (q & 1)) << 4);
+// Bank rules.  One ds_read_b64_tr_b16 serves 32 lanes = 8 pixels x 32 bytes per cycle, and a 32-lane
+// group of a fragment read holds pixels p..p+3 and p+4..p+7 of the tile (pixel_of() below).
+// dy tile: [256][NB] bf16, the 8 rows of a group are consecutive.  NB = 64 -> 128-byte rows (two
+// rows span the 64 banks): 32-byte column group ^ row bits 1-2; NB = 32 -> 64-byte rows (four
+// rows span the banks): 32-byte column group ^ row bit 2.
+template <int NB> __device__ __forceinline__ int dy_swz(int r);
+template <> __device__ __forceinline__ int dy_swz<64>(int r) { return (r >> 1) & 3; }
+template <> __device__ __forceinline__ int dy_swz<32>(int r) { return (r >> 2) & 1; }
+template <int NB> __device__ __forceinline__ int dy_off(int r, int q /*16-byte chunk*/) {
+  return r * (NB * 2) + ((((q >> 1) ^ dy_swz<NB>(r)) << 1 | (q & 1)) << 4);
 }
-// x halo tile: [rows][32] bf16 = 64-byte rows, same rule as dy_off<32>.
-__device__ __forceinline__ int xh_off(int r, int q) { return dy_off<32>(r, q); }
+// x halo tile: [rows][32] bf16 = 64-byte rows (four rows span the banks).  The two 4-pixel runs of
+// a group lie 4 halo rows apart (images 8 and more wide: same image row or, 8 wide, the next one
+// at a pitch of 16) or one image row = 8 halo rows apart (4-wide images, pitch 8): the 32-byte half
+// is flipped by that row bit.
+template <bool RP> __device__ __forceinline__ int xh_swz(int r) { return (r >> (RP ? 3 : 2)) & 1; }
+template <bool RP> __device__ __forceinline__ int xh_off(int r, int q) {
+  return r * 64 + ((((q >> 1) ^ xh_swz<RP>(r)) << 1 | (q & 1)) << 4);
+}
+// Pixel (inside a 32-pixel k-step) that MFMA k-slot (g = lane>>4, q = (lane&15)>>2, half h) stands for:
+// both operands use the same map, so any order is a valid reduction order.
+__device__ __forceinline__ int pixel_of(int g, int q, int h) { return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + q; }
 
 __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
   typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
@@ -81,9 +94,7 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
 #pragma unroll
     for (int i = 0; i < DY_PW; ++i) {
       const int row = (lw + 4 * i) * RPP + lane / DY_CPR, pos = lane % DY_CPR;
-      int c;
-      if (NB == 64) { const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1); c = (((pos >> 1) ^ f) << 1) | (pos & 1); }
-      else { c = (((pos >> 1) ^ ((row >> 3) & 1)) << 1) | (pos & 1); }
+      const int c = (((pos >> 1) ^ dy_swz<NB>(row)) << 1) | (pos & 1);
       dy_voff[i] = n0 + c * 8 < a.Na ? (unsigned)(row * a.dy_cs + c * 8) * 2u : OOB;
     }
     // x halo: piece q covers halo rows [16q, 16q+16); offsets are bytes from (tile's first pixel - one image row)
@@ -102,7 +113,7 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
       const bool top = hy == 0, bot = hy == uR1;
       const bool on = (q < npieces) & (hr < (unsigned)a.HR) & (hx - 1u < uW) & !((top | bot) & single);
       const int pix = (int)(__umul24(g, RW) + __umul24(hy, uW) + hx) - (int)(uW + 1u) + a.W;   // + one image row: never negative
-      const int c = (((pos4 >> 1) ^ (int)((hr >> 3) & 1u)) << 1) | (pos4 & 1);
+      const int c = (((pos4 >> 1) ^ xh_swz<RP>((int)hr)) << 1) | (pos4 & 1);
       x_voff[i] = on ? (unsigned)(__mul24(pix, a.x_cs) + c * 8) * 2u : OOB;
       topmask |= (unsigned)(on & top) << i;
       botmask |= (unsigned)(on & bot) << i;
@@ -146,28 +157,34 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
   const int combo = wave % COMBOS, pg = wave / COMBOS;
   const int ct = combo & 1, np = combo >> 1;
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-  int a_addr[KSP][2][2];      // dy fragment addresses [k-step][n-tile][row half]
-  int b_addr[KSP][2][3];      // x fragment addresses [k-step][row half][tx]
+  // dy fragment addresses: the swizzle depends on pixel bits 1-2 only (q and g&1), so the address
+  // of k-step k, row half h is a compile-time offset from one base per n-tile
+  constexpr int ROWB = NB * 2;
+  int a_base[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = np * 32 + nt * 16 + 4 * pp;                    // channel inside the dy tile
+    a_base[nt] = dy_off<NB>(pg * KSP * 32 + pixel_of(g, q, 0), col >> 3) + (col & 7) * 2;
+  }
+  // x fragment addresses [k-step][row half][tx]; 4-wide images: a horizontal shift never carries
+  // into the swizzle bit, so tx is a compile-time offset from [..][0] there
+  int b_addr[KSP][2][RP ? 1 : 3];
 #pragma unroll
   for (int k = 0; k < KSP; ++k) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int pl = (pg * KSP + k) * 32 + 8 * g + q + 4 * h;      // pixel inside the tile
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int col = np * 32 + nt * 16 + 4 * pp;                // channel inside the dy tile
-        a_addr[k][nt][h] = dy_off<NB>(pl, col >> 3) + (col & 7) * 2;
-      }
+      const int pl = (pg * KSP + k) * 32 + pixel_of(g, q, h);      // pixel inside the tile
       const int gi = (int)fdiv((uint32_t)pl, a.d_rw), rem = pl - gi * (a.R * a.W);
       const int y = (int)fdiv((uint32_t)rem, a.d_w), xx = rem - y * a.W;
       const int hrow = gi * grp_rows + y * a.pitch + xx;            // halo row of tap (0,0)
+      const int col = ct * 16 + 4 * pp;
 #pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        const int col = ct * 16 + 4 * pp;
-        b_addr[k][h][tx] = DY_BYTES + xh_off(hrow + tx, col >> 3) + (col & 7) * 2;
-      }
+      for (int tx = 0; tx < (RP ? 1 : 3); ++tx) b_addr[k][h][tx] = DY_BYTES + xh_off<RP>(hrow + tx, col >> 3) + (col & 7) * 2;
     }
   }
+  // 4-wide images: a vertical shift of one image row (8 halo rows) flips the swizzle bit, i.e. the
+  // 32-byte half every address of this lane points into: +32 or -32, the same for all of them
+  const int flipd = RP ? ((b_addr[0][0][0] & 32) ? -32 : 32) : 0;
   const int ty_bytes = a.pitch * 64;
 
   f32x4_t acc[9][2], accr[2];
@@ -183,13 +200,12 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
     // are read while the MFMAs of step i issue (two register sets, static indices)
     bf16x8_t af[2][2], bfr[2];
     auto read_a = [&](int k, int set) {
-      af[set][0] = tr_pair(S + a_addr[k][0][0], S + a_addr[k][0][1]);
-      af[set][1] = tr_pair(S + a_addr[k][1][0], S + a_addr[k][1][1]);
+      af[set][0] = tr_pair(S + a_base[0] + k * 32 * ROWB, S + a_base[0] + k * 32 * ROWB + 8 * ROWB);
+      af[set][1] = tr_pair(S + a_base[1] + k * 32 * ROWB, S + a_base[1] + k * 32 * ROWB + 8 * ROWB);
     };
     auto read_b = [&](int k, int tp, int set) {
-      const char* Sy = S + (tp / 3) * ty_bytes;
-      const int flip = (RP && ((tp / 3) & 1)) ? 32 : 0;
-      bfr[set] = tr_pair(Sy + (b_addr[k][0][tp % 3] ^ flip), Sy + (b_addr[k][1][tp % 3] ^ flip));
+      const char* Sy = S + (tp / 3) * ty_bytes + (((tp / 3) & 1) ? flipd : 0) + (RP ? (tp % 3) * 64 : 0);
+      bfr[set] = tr_pair(Sy + b_addr[k][0][RP ? 0 : tp % 3], Sy + b_addr[k][1][RP ? 0 : tp % 3]);
     };
     read_a(0, 0);
     read_b(0, 0, 0);
