@@ -58,6 +58,9 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
   return u.v;
 }
 
+template <typename V> __device__ __forceinline__ void hw_pin1(V v) { asm volatile("" ::"s"(v)); }
+template <typename... A> __device__ __forceinline__ void hw_pin(A... v) { (hw_pin1(v), ...); }
+
 // Work of workgroup (bx, by, bz) = (n-block, c-block, pixel split) of one layer.
 // RP: 4-wide images, halo pitch 8 -- a vertical tap shift of one row flips bit 3 of the halo row, i.e. the
 // swizzle bit: odd ty reads the other 32-byte half (the rule the conv kernels use for these images).
@@ -71,6 +74,9 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
   constexpr int X_BYTES = kHwMaxHalo * 64;
   constexpr int STAGE = DY_BYTES + X_BYTES;
   constexpr int DY_CPR = NB / 8;               // 16-byte chunks per dy row
+  // every argument is fetched here, in one batch of scalar loads, not as dependent round trips at first use
+  hw_pin(a.dy, a.x, a.part, a.rowsum, a.dy_cs, a.dy_co, a.Na, a.x_cs, a.x_co, a.Cb, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles,
+         a.tiles_per_split, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift, a.d_bands.mul, a.d_bands.shift);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n0 = bx * NB, c0 = by * 32, z = bz;
   const T* __restrict__ pdy = (const T*)a.dy;
@@ -90,12 +96,28 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
     constexpr int RPP = 1024 / (NB * 2);                                  // dy rows per piece
     constexpr int X_PW = kHwMaxHalo / 16 / 4;                             // x pieces per loader wave
     // dy: lane L of piece p fills chunk position L % DY_CPR of row p*RPP + L / DY_CPR with the channel chunk the swizzle puts there
+    // The first tile's pieces are issued as soon as their offsets exist: dy first (its offsets are
+    // cheap), then each halo piece as the geometry loop produces it.
+    auto dy_rsrc = [&](int tile) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pdy + ((int64_t)tile * 256 * a.dy_cs + a.dy_co + n0)), 0, 0x7fffffff, 0x00020000);
+    };
+    auto x_rsrc = [&](int tile) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(px + ((int64_t)tile * 256 * a.x_cs + a.x_co + c0 - (int64_t)a.W * a.x_cs)), 0,
+                                               0x7fffffff, 0x00020000);
+    };
+    auto dma = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, char* dst) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+    };
     unsigned dy_voff[DY_PW];
+    {
+      const __amdgpu_buffer_rsrc_t rd0 = dy_rsrc(t_begin);
 #pragma unroll
-    for (int i = 0; i < DY_PW; ++i) {
-      const int row = (lw + 4 * i) * RPP + lane / DY_CPR, pos = lane % DY_CPR;
-      const int c = (((pos >> 1) ^ dy_swz<NB>(row)) << 1) | (pos & 1);
-      dy_voff[i] = n0 + c * 8 < a.Na ? (unsigned)(row * a.dy_cs + c * 8) * 2u : OOB;
+      for (int i = 0; i < DY_PW; ++i) {
+        const int row = (lw + 4 * i) * RPP + lane / DY_CPR, pos = lane % DY_CPR;
+        const int c = (((pos >> 1) ^ dy_swz<NB>(row)) << 1) | (pos & 1);
+        dy_voff[i] = n0 + c * 8 < a.Na ? (unsigned)(row * a.dy_cs + c * 8) * 2u : OOB;
+        dma(rd0, dy_voff[i], smem + lw * 1024 + i * 4096);
+      }
     }
     // x halo: piece q covers halo rows [16q, 16q+16); offsets are bytes from (tile's first pixel - one image row)
     const int l4 = lane >> 2, pos4 = lane & 3;
@@ -103,6 +125,9 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
     const unsigned uW = (unsigned)a.W, uR1 = (unsigned)a.R + 1u, RW = (unsigned)(a.R * a.W);
     const bool single = a.bands == 1;
     const int npieces = (a.HR + 15) / 16;
+    const int band0 = t_begin - (int)fdiv((uint32_t)t_begin, a.d_bands) * a.bands;
+    const bool ztop0 = !single && band0 == 0, zbot0 = !single && band0 == a.bands - 1;
+    const __amdgpu_buffer_rsrc_t rx0 = x_rsrc(t_begin);
     unsigned x_voff[X_PW], topmask = 0, botmask = 0, skipmask = 0;
 #pragma unroll
     for (int i = 0; i < X_PW; ++i) {
@@ -119,31 +144,26 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
       botmask |= (unsigned)(on & bot) << i;
       const bool any = __builtin_amdgcn_ballot_w64(on) != 0;
       skipmask |= (unsigned)(!any) << i;
-      if (!any && q < npieces) {        // an all-padding piece: zeroed once in both stages, no DMA ever writes it
+      if (any) dma(rx0, ((ztop0 & on & top) | (zbot0 & on & bot)) ? OOB : x_voff[i], smem + DY_BYTES + q * 1024);
+      else if (q < npieces) {           // an all-padding piece: zeroed once in both stages, no DMA ever writes it
         *(u32x4_t*)(smem + DY_BYTES + q * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
         *(u32x4_t*)(smem + STAGE + DY_BYTES + q * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
       }
     }
     auto issue_tile = [&](int tile, int buf) {
       char* D = smem + buf * STAGE + lw * 1024;
-      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<T*>(pdy + ((int64_t)tile * 256 * a.dy_cs + a.dy_co + n0)), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rd = dy_rsrc(tile);
 #pragma unroll
-      for (int i = 0; i < DY_PW; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(D + i * 4096), 16, (int)dy_voff[i], 0, 0, 0);
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<T*>(px + ((int64_t)tile * 256 * a.x_cs + a.x_co + c0 - (int64_t)a.W * a.x_cs)), 0, 0x7fffffff, 0x00020000);
+      for (int i = 0; i < DY_PW; ++i) dma(rd, dy_voff[i], D + i * 4096);
+      const __amdgpu_buffer_rsrc_t rx = x_rsrc(tile);
       const int band = tile - (int)fdiv((uint32_t)tile, a.d_bands) * a.bands;
       const unsigned zmask = single ? 0u : ((band == 0 ? topmask : 0u) | (band == a.bands - 1 ? botmask : 0u));
       char* X = D + DY_BYTES;
 #pragma unroll
       for (int i = 0; i < X_PW; ++i)
-        if (!((skipmask >> i) & 1))
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(X + i * 4096), 16,
-                                                   (int)(((zmask >> i) & 1) ? OOB : x_voff[i]), 0, 0, 0);
+        if (!((skipmask >> i) & 1)) dma(rx, ((zmask >> i) & 1) ? OOB : x_voff[i], X + i * 4096);
     };
-    issue_tile(t_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the first tile and the one-time zero stores
     __builtin_amdgcn_s_barrier();
     for (int tile = t_begin; tile < t_end; ++tile) {
       if (tile + 1 < t_end) issue_tile(tile + 1, (tile + 1 - t_begin) & 1);
