@@ -196,6 +196,27 @@ def test_maxpool_known_answers(ua, dtype, golden):
         assert rel(fused, rnd(dtype, (gx + sk) * (x > 0))) < 1e-7
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 8, 12), (2, 256, 4, 4), (2, 32, 32, 32), (5, 128, 2, 6), (1, 40, 6, 4), (2, 512, 2, 2)])
+def test_maxpool_bwd_bf16_even_images(ua, shape):
+    """bf16, even H and W, channel counts from one 16-byte group per pixel up to 64 of them: values quantised so
+    that most windows hold ties, exact routing to the first maximum, with and without the fused skip gradient."""
+    ops = ua.ops
+    B, C, H, W = shape
+    dtype = torch.bfloat16
+    x = torch.round(gen(B, C, H, W, seed=11, shift=0.5) * 6) / 4          # few distinct values: many ties
+    xr = x.clone().requires_grad_(True)
+    y = O.maxpool2(xr)
+    gy = rnd(dtype, gen(*y.shape, seed=12, shift=0.5))
+    y.backward(gy)
+    xn = ops.to_nhwc(x.cuda(), dtype)
+    gxn = ops.maxpool2_bwd(xn, ops.to_nhwc(gy.cuda(), dtype), C)
+    assert torch.equal(ops.from_nhwc(gxn, C).cpu(), xr.grad)
+    sk = rnd(dtype, gen(*x.shape, seed=13, shift=0.5))
+    fused = ops.from_nhwc(ops.maxpool2_bwd(xn, ops.to_nhwc(gy.cuda(), dtype), C, dskip=ops.to_nhwc(sk.cuda(), dtype),
+                                           relu_mask=True), C).cpu()
+    assert torch.equal(fused, rnd(dtype, (xr.grad + sk) * (x > 0)))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(3, 32, 16, 5, 7), (2, 64, 32, 8, 8), (2, 8, 4, 3, 3), (4, 512, 256, 2, 2),
                                    (3, 128, 64, 7, 5), (2, 64, 24, 6, 6),
