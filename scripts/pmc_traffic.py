@@ -7,25 +7,31 @@ Both counters are in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of
 reads at 64 bytes and is doubled (checked here on adam_kernel, whose traffic is known exactly:
 4 reads and 3 writes of the flat parameter buffer); WRITE_SIZE is exact."""
 import json
-import re
 import sqlite3
 import sys
 
-NAMES = {"hconv_kernelIDF16bLi4ELi640": "hconv_256x64", "hconv_kernelIDF16bLi2ELi640": "hconv_256x32",
-         "hconv_kernelIDF16bLi2ELi768": "hconv_256x32_h768", "hwgrad_kernel<64>": "hwgrad_64x32x9",
-         "hwgrad_kernel<32>": "hwgrad_32x32x9", "adam_kernel": "adam", "pconv_kernelIDF16bLi4": "pconv_64x64_k4",
-         "maxpool2_bwd": "maxpool2_bwd", "maxpool2_fwd": "maxpool2_fwd", "wgrad_kernelIDF16bLi3": "wgrad_64x64_pos"}
+# substring of the profiler's kernel name -> the name bench.py reports for it
+NAMES = {"dconv_kernel<4, false>": "dconv_256x64", "dconv_kernel<4, true>": "dconv_256x64_rp",
+         "dconv_kernel<2, false>": "dconv_256x32", "dconv_kernel<2, true>": "dconv_256x32_rp",
+         "dconv_kernel<1, false>": "dconv_256x16", "dconv_kernel<1, true>": "dconv_256x16_rp",
+         "hwgrad_kernel<64,": "hwgrad_64x32x9", "hwgrad_kernel<32,": "hwgrad_32x32x9", "adam_kernel": "adam",
+         "pconv_kernel<__bf16, 4>": "pconv_64x64_k4", "pconv_kernelIDF16bLi4": "pconv_64x64_k4",
+         "maxpool2_bwd": "maxpool2_bwd", "maxpool2_fwd": "maxpool2_fwd", "tconv_fwd": "tconv_fwd", "tconv_dgrad": "tconv_dgrad",
+         "finalize": "finalize", "head_bwd": "head_bwd", "head_fwd": "head_fwd", "nchw_to_nhwc": "nchw_to_nhwc"}
 
 
 def per_kernel(db, counter):
+    """short name -> (mean bytes per launch, launches), the variants that share a short name pooled."""
     c = sqlite3.connect(db)
-    out = {}
+    acc = {}
     for k, v, n in c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? "
                              "group by kernel_name", (counter,)):
         for pat, short in NAMES.items():
             if pat in k:
-                out[short] = (v * 1024.0, n)
-    return out
+                tot, cnt = acc.get(short, (0.0, 0))
+                acc[short] = (tot + v * 1024.0 * n, cnt + n)
+                break
+    return {k: (tot / cnt, cnt) for k, (tot, cnt) in acc.items()}
 
 
 def main():
