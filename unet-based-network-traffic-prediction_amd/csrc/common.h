@@ -129,7 +129,9 @@ struct Conv3WgradCall {
   void* ws; size_t ws_bytes;
   int Cin, split, Cout;
 };
-struct HwgradBatch { HwgradArgs layer[2]; int n, wgs0; };   // wgs0 = workgroups of layer 0
+// wgs0 = workgroup ids of layer 0.  xcd_order: ids are dealt to the 8 XCDs so that the workgroups that read the
+// same dy tiles (one n-block and pixel split, all its c-blocks) share an XCD and its L2; rot[i] rotates layer i's deal.
+struct HwgradBatch { HwgradArgs layer[2]; int n, wgs0; int xcd_order; int rot[2]; };
 int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const char** name);
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
 int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);

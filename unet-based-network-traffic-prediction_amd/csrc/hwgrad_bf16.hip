@@ -334,8 +334,18 @@ __global__ __launch_bounds__(768) void hwgrad_kernel(const HwgradBatch p) {
   if (li) id -= p.wgs0;
   const HwgradArgs& a = p.layer[li];
   const int gx = (a.Na + NB - 1) / NB, gy = a.Cb / 32;
-  const int bz = id / (gx * gy), rem = id - bz * (gx * gy);
-  const int by = rem / gx, bx = rem - by * gx;
+  int bx, by, bz;
+  if (p.xcd_order) {
+    // id = slot*8 + xcd; the XCD's slots run over its units (n-block, split), gy workgroups each
+    const int xcd = id & 7, slot = id >> 3;
+    const int unit = (slot / gy) * 8 + ((xcd + 8 - p.rot[li]) & 7);   // unit u sits on XCD (u + rot) % 8
+    if (unit >= gx * a.splits) return;          // a hole of the deal: 8 does not divide the unit count
+    by = slot % gy; bz = unit / gx; bx = unit - bz * gx;
+  } else {
+    bz = id / (gx * gy);
+    const int rem = id - bz * (gx * gy);
+    by = rem / gx; bx = rem - by * gx;
+  }
   hwgrad_body<NB, RP>(a, bx, by, bz, smem);
 }
 
@@ -361,8 +371,18 @@ int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const cha
     a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
     p.layer[i] = a;
   }
-  p.wgs0 = hwgrad_wgs(p.layer[0], NB);
-  const int total = p.wgs0 + (n > 1 ? hwgrad_wgs(p.layer[1], NB) : 0);
+  // XCD-aware order when no XCD (32 CUs) would be dealt more than 32 workgroups, else the plain one
+  auto units = [&](const HwgradArgs& a) { return (a.Na + NB - 1) / NB * a.splits; };
+  auto dealt = [&](const HwgradArgs& a) { return (units(a) + 7) / 8 * 8 * (a.Cb / 32); };
+  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  p.rot[0] = 0; p.rot[1] = n > 1 ? units(p.layer[0]) % 8 : 0;
+  for (int i = 0; i < n; ++i)
+    for (int u = 0; u < units(p.layer[i]); ++u) load[(u + p.rot[i]) % 8] += p.layer[i].Cb / 32;
+  int worst = 0;
+  for (int x = 0; x < 8; ++x) worst = load[x] > worst ? load[x] : worst;
+  p.xcd_order = worst <= 32;
+  p.wgs0 = p.xcd_order ? dealt(p.layer[0]) : hwgrad_wgs(p.layer[0], NB);
+  const int total = p.wgs0 + (n > 1 ? (p.xcd_order ? dealt(p.layer[1]) : hwgrad_wgs(p.layer[1], NB)) : 0);
   const bool rp = p.layer[0].pitch == 8;
   for (int i = 0; i < n; ++i) MI_REQUIRE((p.layer[i].pitch == 8) == rp, "hwgrad: layers of one launch must share the halo pitch rule");
   if (NB == 64) {
