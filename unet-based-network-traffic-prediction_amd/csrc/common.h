@@ -107,6 +107,7 @@ struct WgradArgs {
   int M;
   FastDiv divHW, divW;
   const void* zero;                        // zero page (filled in by launch_wgrad)
+  int gx, gy, usize, units;                // workgroup deal (filled in by the launcher): see wgrad_kernel
 };
 // Halo-tile weight gradient (hwgrad_bf16.hip): 3x3 convs on evenly tiling images, bf16 only.
 struct HwgradArgs {

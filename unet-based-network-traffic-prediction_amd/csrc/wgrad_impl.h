@@ -94,7 +94,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, z = blockIdx.z;
+  // Workgroup ids are dealt to the 8 XCDs (id % 8) in units that read the same pixels -- a whole
+  // pixel split, or one n-block of it when the split has more than 32 tiles -- so the operand tiles a
+  // unit shares come from one L2 instead of being fetched by every XCD.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int unit = (slot / a.usize) * 8 + xcd, mem = slot % a.usize;
+  if (unit >= a.units) return;                 // a hole of the deal: 8 does not divide the unit count
+  int bx, by, z;
+  if (a.usize == a.gx * a.gy) { z = unit; by = mem / a.gx; bx = mem - by * a.gx; }
+  else { z = unit / a.gx; bx = unit - z * a.gx; by = mem; }
+  const int n0 = bx * 64, k0 = by * 64;
   const int K = a.taps * a.Cb;
   const T* __restrict__ pa = (const T*)a.a;
   const T* __restrict__ pb = (const T*)a.b;
@@ -198,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
   // row sums need every pixel: in G_3x3P only the centre tap's list has them all
   const int rows_ky = MODE == G_3x3P ? 4 * a.Cb / 64 : 0;
-  const bool do_rows = a.rowsum != nullptr && (int)blockIdx.y == rows_ky && wc == 0;
-  const bool do_cols = a.colsum != nullptr && blockIdx.x == 0 && wr == 0;
+  const bool do_rows = a.rowsum != nullptr && by == rows_ky && wc == 0;
+  const bool do_cols = a.colsum != nullptr && bx == 0 && wr == 0;
   const auto ones = ones_frag(T());
 
   auto compute = [&](int buf) {
@@ -274,9 +283,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 }
 
 template <typename T>
-static int launch_wgrad_t(const WgradArgs& a, hipStream_t s, const char** name) {
+static int launch_wgrad_t(const WgradArgs& a_in, hipStream_t s, const char** name) {
+  WgradArgs a = a_in;
   const int K = a.taps * a.Cb;
-  dim3 grid((a.Na + 63) / 64, (K + 63) / 64, a.splits);
+  a.gx = (a.Na + 63) / 64; a.gy = (K + 63) / 64;
+  if (a.gx * a.gy <= 32) { a.usize = a.gx * a.gy; a.units = a.splits; }
+  else { a.usize = a.gy; a.units = a.splits * a.gx; }
+  dim3 grid((a.units + 7) / 8 * 8 * a.usize);
   if (name) *name = "wgrad_64x64";
   switch (a.mode) {
     case G_3x3: hipLaunchKernelGGL((wgrad_kernel<T, G_3x3>), grid, dim3(256), 0, s, a); break;
