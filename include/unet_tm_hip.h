@@ -168,6 +168,7 @@ size_t mi_conv1x1_head_ws_bytes(int Cin, int Cout);
  * out3 (device, 3 floats) = { mean((pred-y)^2), sum|pred-y|, sum (pred-y)^2 }.
  * If dpred != NULL also writes dpred = gscale * 2*(pred-y)/n  (gscale_dev, if not NULL,
  * is a device scalar multiplied in: the upstream gradient of the loss).
+ * out3 may be NULL when dpred is not (the backward pass of the loss: gradient only, one launch).
  * ws: mi_mse_ws_bytes(n). Deterministic two-pass reduction. */
 int mi_mse_fwd_bwd(const float* pred, const float* target, int64_t n, float* out3,
                    float* dpred, float gscale, const float* gscale_dev, void* ws, size_t ws_bytes, mi_stream s);

@@ -291,6 +291,8 @@ def test_mse(ua):
         gs = torch.tensor([0.25], device="cuda")
         _, dp2 = ops.mse_fwd_bwd(p.cuda(), y.cuda(), gscale_dev=gs)
         assert rel(dp2.cpu(), 0.25 * pr.grad) < 2e-7
+        none3, dp3 = ops.mse_fwd_bwd(p.cuda(), y.cuda(), gscale_dev=gs, want_sums=False)   # gradient only (the loss's backward)
+        assert none3 is None and torch.equal(dp3, dp2)
     with pytest.raises(ValueError):
         ops.mse_fwd_bwd(torch.zeros(2, 3, device="cuda"), torch.zeros(3, 2, device="cuda"))
 

@@ -538,7 +538,7 @@ int mi_conv1x1_head_bwd(const void* x, int xcs, int xco, const float* w, const f
 size_t mi_mse_ws_bytes(int64_t n) { return mse_ws_bytes(n); }
 int mi_mse_fwd_bwd(const float* pred, const float* target, int64_t n, float* out3, float* dpred, float gscale,
                    const float* gscale_dev, void* ws, size_t ws_bytes, mi_stream s) {
-  MI_REQUIRE(pred && target && out3 && ws, "mse: null pointer");
+  MI_REQUIRE(pred && target && ws && (out3 || dpred), "mse: null pointer");
   return launch_mse(pred, target, n, out3, dpred, gscale, gscale_dev, ws, ws_bytes, (hipStream_t)s);
 }
 

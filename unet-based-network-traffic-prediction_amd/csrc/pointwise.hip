@@ -1119,6 +1119,7 @@ size_t mse_ws_bytes(int64_t) { return (size_t)kMseBlocks * 2 * sizeof(float); }
 int launch_mse(const float* pred, const float* target, int64_t n, float* out3, float* dpred, float gscale,
                const float* gscale_dev, void* ws, size_t ws_bytes, hipStream_t s) {
   MI_REQUIRE(n > 0, "mse: empty input");
+  MI_REQUIRE(out3 != nullptr || dpred != nullptr, "mse: neither the sums nor the gradient requested");
   if (ws_bytes < mse_ws_bytes(n)) return fail(MI_ESIZE, "mse: workspace too small");
   MI_REQUIRE(((uintptr_t)pred % 16 == 0) && ((uintptr_t)target % 16 == 0) && ((uintptr_t)dpred % 16 == 0),
              "mse: pointers must be 16-byte aligned");
@@ -1129,6 +1130,7 @@ int launch_mse(const float* pred, const float* target, int64_t n, float* out3, f
   hipLaunchKernelGGL(mse_partial_kernel, dim3(nblocks), dim3(256), 0, s, pred, target, n, dpred, coef, gscale_dev, (float*)ws);
   int rc = check_hip(hipGetLastError(), "mse_partial");
   if (rc) return rc;
+  if (out3 == nullptr) return MI_OK;            // gradient only: the sums are not wanted
   hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, nblocks, 1.0 / (double)n, out3);
   return check_hip(hipGetLastError(), "mse_final");
 }

@@ -25,7 +25,7 @@ class _MSEFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         pred, target = ctx.saved_tensors
         g = grad_out.contiguous().float()
-        _, dpred = ops.mse_fwd_bwd(pred, target, want_grad=True, gscale=1.0, gscale_dev=g)
+        _, dpred = ops.mse_fwd_bwd(pred, target, want_grad=True, gscale=1.0, gscale_dev=g, want_sums=False)
         return dpred, None, None
 
 

@@ -208,18 +208,18 @@ def head_bwd(x, weight, dpred, Cin, Cout, relu_mask=True, alpha=1.0, beta=0.0):
 
 
 # ------------------------------------------------------------------ loss
-def mse_fwd_bwd(pred, target, want_grad=True, gscale=1.0, gscale_dev: Optional[torch.Tensor] = None):
-    """Returns (out3, dpred): out3 = [mean sq err, sum |d|, sum d^2] (device fp32)."""
+def mse_fwd_bwd(pred, target, want_grad=True, gscale=1.0, gscale_dev: Optional[torch.Tensor] = None, want_sums=True):
+    """Returns (out3, dpred): out3 = [mean sq err, sum |d|, sum d^2] (device fp32), or None without want_sums."""
     _need_cuda(pred, target)
     if pred.shape != target.shape:
         raise ValueError(f"mse: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
     pred, target = pred.contiguous(), target.contiguous()
     n = pred.numel()
-    out3 = torch.empty(3, device=pred.device, dtype=torch.float32)
+    out3 = torch.empty(3, device=pred.device, dtype=torch.float32) if want_sums else None
     dpred = torch.empty_like(pred) if want_grad else None
     nbytes = lib().mi_mse_ws_bytes(n)
     ws = torch.empty(nbytes, device=pred.device, dtype=torch.uint8)
-    check(lib().mi_mse_fwd_bwd(pred.data_ptr(), target.data_ptr(), n, out3.data_ptr(),
+    check(lib().mi_mse_fwd_bwd(pred.data_ptr(), target.data_ptr(), n, out3.data_ptr() if want_sums else None,
                                dpred.data_ptr() if want_grad else None, gscale,
                                gscale_dev.data_ptr() if gscale_dev is not None else None,
                                ws.data_ptr(), nbytes, _stream()), "mse")
