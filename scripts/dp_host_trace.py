@@ -54,6 +54,10 @@ def main():
         red.reduce_async = lambda t: red._pending.append(dist.all_reduce(dummy, async_op=True))
     if a.sync_op:
         red.reduce_async = lambda t: dist.all_reduce(t)
+    L = unet_amd.lib()
+    for fn in ("mi_unet_backward", "mi_unet_forward", "mi_adam_step", "mi_mse_fwd_bwd"):
+        if hasattr(L, fn):
+            setattr(L, fn, timed("C " + fn, getattr(L, fn)))
     red.reduce_async = timed("reduce_async", red.reduce_async)
     red.wait_all = timed("wait_all", red.wait_all)
 
@@ -77,7 +81,8 @@ def main():
     torch.cuda.synchronize()
     total = time.perf_counter() - t
     print(f"buckets of {a.bucket_mb} MiB, {a.collective}: {total / a.steps * 1e3:.4f} ms/step, host {host / a.steps * 1e3:.4f} ms/step")
-    for k in ("forward", "loss+zero_grad", "backward", "reduce_async", "wait_all", "optimizer"):
+    for k in ("forward", "C mi_unet_forward", "loss+zero_grad", "C mi_mse_fwd_bwd", "backward", "C mi_unet_backward", "reduce_async",
+              "wait_all", "optimizer", "C mi_adam_step"):
         if cnt[k]:
             print(f"  {k:16s} {acc[k] / a.steps * 1e6:8.1f} us/step in {cnt[k] / a.steps:.1f} calls")
     dist.destroy_process_group()

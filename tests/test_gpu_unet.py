@@ -594,9 +594,10 @@ def test_data_parallel_prescale_reaches_every_gradient(dtype, feats, cout, hw):
     m._dp = None
 
 
-def test_one_rank_rccl_group_runs_the_collective_path():
-    """A one-rank RCCL group: the asynchronous all-reduces of the gradient buckets and the
-    stream hand-over to the optimizer run for real; the averaged gradient of one rank is its own."""
+def test_one_rank_rccl_group_runs_the_collective_path(monkeypatch):
+    """A one-rank RCCL group: the all-reduces of the gradient buckets and the stream hand-over to the
+    optimizer run for real; the averaged gradient of one rank is its own.  Also with captured launch
+    graphs, where a bucket's call must join its streams (a capture cannot end with a deferred join)."""
     import torch.distributed as dist
     import unet_amd
     if dist.is_initialized():
@@ -628,6 +629,17 @@ def test_one_rank_rccl_group_runs_the_collective_path():
         # several buckets, reduced behind the plan's second stream without joining the streams in between
         assert len(m._dp.buckets_for(m.last_plan)) >= 2
         assert getattr(m.last_plan, "side_stream", None) is not None
+        monkeypatch.setenv("UNET_TM_GRAPH", "1")
+        torch.manual_seed(0)
+        mg = unet_amd.UNet(12, 1, (8, 16, 32, 64), compute_dtype="fp32").cuda()
+        unet_amd.GradientReducer(bucket_bytes=64 << 10, force=True).attach(mg)
+        for _ in range(4):                       # replayed from the captured graphs from the third pass on
+            for p in mg.parameters():
+                p.grad = None
+            crit(mg(X), Y).backward()
+        torch.cuda.synchronize()
+        for a, p in zip(g0, mg.parameters()):
+            assert torch.equal(a, p.grad)
     finally:
         dist.destroy_process_group()
 

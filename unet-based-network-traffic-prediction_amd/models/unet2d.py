@@ -394,7 +394,7 @@ class UNet(nn.Module):
             # current stream, and the waits below are issued there.
             side = L.mi_unet_plan_side_stream(plan.handle, stream)
             ext = None
-            if side:
+            if side and not plan.graph_mode:      # a captured launch sequence must end joined: no deferred join there
                 ext = plan.side_stream if getattr(plan, "side_stream", None) is not None else torch.cuda.ExternalStream(side)
                 plan.side_stream = ext
             check(L.mi_unet_plan_defer_join(plan.handle, 1 if ext is not None else 0), "unet_plan_defer_join")
