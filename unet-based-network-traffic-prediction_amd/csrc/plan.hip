@@ -25,6 +25,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace mi {
@@ -102,15 +103,15 @@ struct mi_unet_plan {
   std::vector<hipEvent_t> sync_pool;
   size_t sync_used;
 
+  // name -> index, filled as tensors and layers are registered (a step looks up ~150 names)
+  std::unordered_map<std::string, int> tensor_index, layer_index;
   int tensor_id(const std::string& n) const {
-    for (size_t i = 0; i < tensors.size(); ++i)
-      if (tensors[i].name == n) return (int)i;
-    return -1;
+    const auto it = tensor_index.find(n);
+    return it == tensor_index.end() ? -1 : it->second;
   }
   int layer_id(const std::string& p) const {
-    for (size_t i = 0; i < layers.size(); ++i)
-      if (layers[i].prefix == p) return (int)i;
-    return -1;
+    const auto it = layer_index.find(p);
+    return it == layer_index.end() ? -1 : it->second;
   }
 };
 
@@ -132,6 +133,7 @@ int add_tensor(mi_unet_plan* P, const std::string& name, int B, int H, int W, in
   t.off = cursor;
   cursor = align_up(cursor + t.bytes, 256);
   P->tensors.push_back(t);
+  P->tensor_index.emplace(name, (int)P->tensors.size() - 1);      // the first registration of a name wins, as a linear search would
   return (int)P->tensors.size() - 1;
 }
 
@@ -504,6 +506,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     Layer l; l.prefix = p; l.kind = kind; l.cin = cin; l.cout = cout; l.split = split;
     l.w_off = l.b_off = 0; l.wf_off = l.wb_off = 0;
     P->layers.push_back(l);
+    P->layer_index.emplace(l.prefix, (int)P->layers.size() - 1);
   };
   int ch = d.in_channels;
   for (int l = 0; l < L; ++l) {
