@@ -774,16 +774,24 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     // a workspace that needs its weights packed may be new: the arrival counters of the few-pixel
     // conv kernel start at zero (the kernel itself leaves them there)
     if (P->ksplit_bytes) RUN(check_hip(hipMemsetAsync(r.ws + P->ksplit_off, 0, kKsplitCounterBytes, r.s), "zero the K-split counters"));
-    PackJobs J;
-    J.n = 0;
-    for (const auto& l : P->layers) {
-      if (l.kind != K_CONV3 && l.kind != K_CONVT) continue;
-      if (J.n == kMaxPackJobs) { RUN(launch_pack_multi(J, dt, r.s)); J.n = 0; }
-      if (!pack_jobs_add(J, r.W(l), r.ws + l.wf_off, train ? r.ws + l.wb_off : nullptr, l.kind == K_CONVT, l.cout, l.cin,
-                         l.split))
-        return fail(MI_EINVAL, "unet_forward: layer too large to pack");
+    // The forward images are needed at once; the backward images (dgrad operands) not before the
+    // backward pass: in training they are packed on the second stream, which has nothing else to do
+    // during a forward pass, and joined at the end of this call.
+    static const bool one_stream = getenv("UNET_TM_PACK_ONE_STREAM") != nullptr;
+    hipStream_t bs = train && !one_stream ? fork_side(r) : r.s;
+    for (int pass = 0; pass < (train ? 2 : 1); ++pass) {
+      hipStream_t ps = pass == 0 ? r.s : bs;
+      PackJobs J;
+      J.n = 0;
+      for (const auto& l : P->layers) {
+        if (l.kind != K_CONV3 && l.kind != K_CONVT) continue;
+        if (J.n == kMaxPackJobs) { RUN(launch_pack_multi(J, dt, ps)); J.n = 0; }
+        if (!pack_jobs_add(J, r.W(l), pass == 0 ? r.ws + l.wf_off : nullptr, pass == 1 ? r.ws + l.wb_off : nullptr,
+                           l.kind == K_CONVT, l.cout, l.cin, l.split))
+          return fail(MI_EINVAL, "unet_forward: layer too large to pack");
+      }
+      RUN(launch_pack_multi(J, dt, ps));
     }
-    RUN(launch_pack_multi(J, dt, r.s));
   }
   View cur = r.view("x");
   for (int l = 0; l < L; ++l) {
@@ -846,6 +854,7 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     RUN(do_conv_fwd(r, c2, u1, u2, B, P->h[l], P->w[l], c2.prefix.c_str()));
     cur = u2;
   }
+  RUN(join_side(r));      // the backward images, if they were packed beside this pass
   }  // PH_BODY
   if (phases & PH_OUT) {
     const Layer& hd = P->layers.back();
