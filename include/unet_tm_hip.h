@@ -6,9 +6,10 @@
  * as void*).  The caller owns all memory: outputs and workspaces are caller-allocated,
  * nothing is retained after a call returns, nothing is freed by the library.  Work is
  * enqueued on the given stream and no entry point waits for the GPU, with ONE exception:
- * mi_unet_plan_prepare() (or, if it was never called, the first mi_unet_backward /
- * mi_unet_plan_side_stream of a process on a given device and caller stream) picks the
- * second stream the weight-gradient kernels run on by timing two trivial kernels, which
+ * mi_unet_plan_prepare() (or, if it was never called, the first training-mode mi_unet_forward
+ * with MI_FWD_REPACK, mi_unet_backward or mi_unet_plan_side_stream of a process on a given device
+ * and caller stream) picks the second stream -- the one the weight-gradient kernels and the packing
+ * of the backward weight images run on -- by timing two trivial kernels, which
  * waits for the caller's stream once.  That choice -- one stream per (device, caller
  * stream), kept for the life of the process -- is the library's only process-wide state.
  * The return value is 0 on success, a negative MI_E* code for an argument error, or a
