@@ -120,7 +120,7 @@ def test_pool_ties_known_answers(golden):
     assert gx[2, 3] == gy[1, 1] and gx[3, 3] == 0                                       # right-column tie
 
 
-def test_flop_counts_match_survey_table():
+def test_flop_counts_of_the_benchmark_configurations():
     assert O.conv_flops_per_sample(12, 1, (32, 64, 128, 256), 16, 16) == (95_633_408, 285_130_752)
     assert O.conv_flops_per_sample(12, 1, (32, 64, 128, 256), 32, 32) == (382_533_632, 1_140_523_008)
     assert O.conv_flops_per_sample(24, 12, (32, 64, 128, 256, 512), 128, 128) == (7_671_382_016, 22_787_653_632)
