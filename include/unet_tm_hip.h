@@ -260,6 +260,9 @@ int mi_unet_plan_tensor_info(const mi_unet_plan* plan, int i, char* name, int na
 int mi_unet_plan_num_segments(const mi_unet_plan* plan);
 int mi_unet_plan_segment_range(const mi_unet_plan* plan, int seg, int64_t* lo, int64_t* hi);
 
+/* The workspace keeps state between calls (packed weights, and counters that the kernels expect
+ * at zero and leave at zero): the FIRST forward on a workspace, and the first after its contents
+ * were overwritten, must carry MI_FWD_REPACK, which packs the weights and initialises that state. */
 #define MI_FWD_REPACK 1      /* parameters changed since the last forward: repack weights */
 #define MI_FWD_TRAIN 2       /* keep what backward needs (also packs dgrad weights) */
 int mi_unet_forward(mi_unet_plan* plan, const float* x_nchw, const float* params_flat, void* ws,
