@@ -12,6 +12,8 @@
  * of the backward weight images run on -- by timing two trivial kernels, which
  * waits for the caller's stream once.  That choice -- one stream per (device, caller
  * stream), kept for the life of the process -- is the library's only process-wide state.
+ * The library reads no environment variable: every switch is a plan option
+ * (mi_unet_plan_set_option) that the host side sets.
  * The return value is 0 on success, a negative MI_E* code for an argument error, or a
  * positive hipError_t.  mi_last_error() returns a thread-local description of the last
  * failure.
@@ -262,7 +264,9 @@ int mi_unet_plan_segment_range(const mi_unet_plan* plan, int seg, int64_t* lo, i
 
 /* The workspace keeps state between calls (packed weights, and counters that the kernels expect
  * at zero and leave at zero): the FIRST forward on a workspace, and the first after its contents
- * were overwritten, must carry MI_FWD_REPACK, which packs the weights and initialises that state. */
+ * were overwritten, must carry MI_FWD_REPACK, which packs the weights and initialises that state.
+ * The plan remembers which workspace addresses it has initialised: a forward without MI_FWD_REPACK,
+ * or a backward, on an address it has not seen returns MI_ESTATE. */
 #define MI_FWD_REPACK 1      /* parameters changed since the last forward: repack weights */
 #define MI_FWD_TRAIN 2       /* keep what backward needs (also packs dgrad weights) */
 int mi_unet_forward(mi_unet_plan* plan, const float* x_nchw, const float* params_flat, void* ws,
@@ -272,6 +276,30 @@ int mi_unet_backward(mi_unet_plan* plan, const float* dpred_nchw, const float* p
                      size_t ws_bytes, float* grads_flat, float alpha, float beta, int seg_lo, int seg_hi,
                      float* dx_nchw, mi_stream s);
 
+/* Plan options (no counterpart in the reference).  All default to 0; set them right after
+ * mi_unet_plan_create.  The Python module maps the environment variables UNET_TM_GRAPH,
+ * UNET_TM_SERIAL_BACKWARD, UNET_TM_DEBUG_STREAMS and UNET_TM_PACK_ONE_STREAM onto them.
+ *   MI_OPT_GRAPH            replay the plan-owned part of forward / backward from captured HIP graphs
+ *                           (pays only where the host cannot keep ahead of the GPU)
+ *   MI_OPT_SERIAL_BACKWARD  keep every kernel on the caller's stream (no second stream at all);
+ *                           must be set before the plan's first training call
+ *   MI_OPT_DEBUG_STREAMS    print the outcome of the second-stream choice on stderr
+ *   MI_OPT_PACK_ONE_STREAM  pack the dgrad weight images on the caller's stream instead of beside
+ *                           the forward pass
+ *   MI_OPT_NO_KSPLIT        never split the K range of a few-pixel 3x3 layer across workgroups (the
+ *                           split exchanges partial tiles through workspace scratch; see below) */
+#define MI_OPT_GRAPH 1
+#define MI_OPT_SERIAL_BACKWARD 2
+#define MI_OPT_DEBUG_STREAMS 3
+#define MI_OPT_PACK_ONE_STREAM 4
+#define MI_OPT_NO_KSPLIT 5
+int mi_unet_plan_set_option(mi_unet_plan* plan, int option, int value);
+/* Where the scratch of the cross-workgroup K split lies in the workspace (total_bytes = 0: this plan
+ * has none): counter_bytes of arrival counters, then partial tiles.  The kernels expect the counters
+ * at zero and leave them at zero; a check can read them back between launches. */
+int mi_unet_plan_ksplit_region(const mi_unet_plan* plan, size_t* ws_offset_bytes, size_t* counter_bytes,
+                               size_t* total_bytes);
+
 /* Bucketed callers (no counterpart in the reference, which is single-device): mi_unet_backward runs
  * the weight-gradient kernels on a second stream of the plan and, by default, makes the caller's
  * stream wait for them before it returns.  With defer_join on, a call over a PARTIAL segment range
@@ -279,7 +307,7 @@ int mi_unet_backward(mi_unet_plan* plan, const float* dpred_nchw, const float* p
  * stream, so a collective enqueued behind mi_unet_plan_side_stream() sees the finished gradient
  * range while the next call's dgrad chain starts without a stall.  The call whose range ends at the
  * last segment joins the two streams as usual.  mi_unet_plan_side_stream returns NULL when the plan
- * runs on one stream (profiling on, UNET_TM_SERIAL_BACKWARD=1, or no stream found that runs
+ * runs on one stream (profiling on, MI_OPT_SERIAL_BACKWARD, or no stream found that runs
  * concurrently with caller_stream): then there is nothing to defer.  The stream is chosen on first
  * use, which synchronises caller_stream once; mi_unet_plan_prepare makes that first use explicit
  * (call it once after creating a plan, outside any latency-critical or captured region).

@@ -22,3 +22,17 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def curve_batches(g):
+    """The batches of a `curve*` fixture (tests/golden/make_golden.py: curve_case): seeded inputs, the
+    target a fixed function of the input."""
+    import torch
+    cin, cout = int(g["meta.cin"]), int(g["meta.cout"])
+    b = int(g["meta.batch"]); h, w = (int(v) for v in g["meta.hw"])
+    out = []
+    for i in range(int(g["meta.n_batches"])):
+        gen = torch.Generator().manual_seed(100 + i)
+        X = torch.rand(b, cin, h, w, generator=gen)
+        out.append((X, X[:, :cout] * 0.5 + 0.25 * X[:, -cout:].flip(-1)))
+    return out

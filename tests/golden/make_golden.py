@@ -18,6 +18,10 @@ Files written next to this script:
   cfg2_b32.npz   default widths, 12ch 32x32 B=32: same
   cfg4_b2.npz    5-level default widths 24->12ch 128x128 B=2: same (8 steps)
   pool_ties.npz  2x2 max-pool known answers incl. tied windows
+  curve240.npz   reduced widths, 12ch 16x16, four batches of 16 in rotation, 240 Adam steps at lr 1e-3:
+                 the loss of every step (a curve that actually descends) and the final test sums
+
+Name cases on the command line to regenerate only those (default: all).
 """
 import os
 import sys
@@ -210,11 +214,52 @@ def pool_ties():
     print("pool_ties: all-zero window grad =", out["even.gx"][0, 0, 0:2, 0:2].tolist())
 
 
+def curve_case(name, cin, cout, features, h, w, batch, n_batches, steps, lr, seed_model=0):
+    """The loop of train.py:382-393 over several batches in rotation, long enough and with a learning
+    rate large enough for the loss to fall by a large factor: every step's loss, and the sums of
+    test.py:39-43 over all batches at the end."""
+    torch.manual_seed(seed_model)
+    model = build_model_from_cfg(make_cfg(cin, cout, features))
+    batches = [synthetic(batch, cin, cout, h, w, seed=100 + i) for i in range(n_batches)]
+    # a learnable target: a fixed smooth function of the input, so the curve has somewhere to go
+    batches = [(X, X[:, :cout] * 0.5 + 0.25 * X[:, -cout:].flip(-1)) for X, _ in batches]
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    crit = torch.nn.MSELoss()
+    losses = []
+    model.train()
+    for s in range(steps):
+        X, Y = batches[s % n_batches]
+        l = crit(model(X), Y)
+        opt.zero_grad()
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    model.eval()
+    abs_sum = sq_sum = 0.0
+    with torch.no_grad():
+        for X, Y in batches:
+            d = model(X) - Y
+            abs_sum += d.abs().sum().item()
+            sq_sum += (d ** 2).sum().item()
+    out = {"meta.cin": cin, "meta.cout": cout, "meta.features": np.array(features), "meta.out_size": np.array((-1, -1)),
+           "meta.batch": batch, "meta.hw": np.array((h, w)), "meta.n_batches": n_batches, "meta.lr": np.float64(lr),
+           "losses": np.array(losses, dtype=np.float64), "eval.abs_sum": np.float64(abs_sum),
+           "eval.sq_sum": np.float64(sq_sum)}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: loss[0]={losses[0]:.6f} loss[{steps // 2}]={losses[steps // 2]:.6f} loss[-1]={losses[-1]:.6f}")
+
+
+CASES = {
+    "small4": lambda: run_case("small4", 12, 1, (4, 8, 16, 32), 16, 16, batch=2),
+    "small5": lambda: run_case("small5", 24, 12, (4, 8, 16, 32, 64), 32, 32, batch=2),
+    "odd": lambda: run_case("odd", 3, 1, (4, 8, 16, 32), 27, 24, batch=2, out_size=(15, 24)),
+    "cfg1_full": lambda: run_case("cfg1_full", 12, 1, (32, 64, 128, 256), 16, 16, batch=32, full=False),
+    "cfg2_b32": lambda: run_case("cfg2_b32", 12, 1, (32, 64, 128, 256), 32, 32, batch=32, full=False),
+    "cfg4_b2": lambda: run_case("cfg4_b2", 24, 12, (32, 64, 128, 256, 512), 128, 128, batch=2, full=False, steps=8),
+    "pool_ties": pool_ties,
+    "curve240": lambda: curve_case("curve240", 12, 1, (8, 16, 32, 64), 16, 16, batch=16, n_batches=4, steps=240, lr=1e-3),
+}
+
 if __name__ == "__main__":
-    run_case("small4", 12, 1, (4, 8, 16, 32), 16, 16, batch=2)
-    run_case("small5", 24, 12, (4, 8, 16, 32, 64), 32, 32, batch=2)
-    run_case("odd", 3, 1, (4, 8, 16, 32), 27, 24, batch=2, out_size=(15, 24))
-    run_case("cfg1_full", 12, 1, (32, 64, 128, 256), 16, 16, batch=32, full=False)
-    run_case("cfg2_b32", 12, 1, (32, 64, 128, 256), 32, 32, batch=32, full=False)
-    run_case("cfg4_b2", 24, 12, (32, 64, 128, 256, 512), 128, 128, batch=2, full=False, steps=8)
-    pool_ties()
+    for case in (sys.argv[1:] or list(CASES)):
+        CASES[case]()

@@ -613,22 +613,30 @@ def test_one_rank_rccl_group_runs_the_collective_path(monkeypatch):
         crit = unet_amd.MSELoss()
         crit(m(X), Y).backward()
         g0 = [p.grad.clone() for p in m.parameters()]
-        unet_amd.GradientReducer(bucket_bytes=64 << 10, force=True).attach(m)
-        unet_amd.broadcast_parameters(m)
-        opt = unet_amd.FusedAdam(m.parameters(), lr=1e-4, model=m)
-        for _ in range(3):
-            loss = crit(m(X), Y)
-            opt.zero_grad()
-            loss.backward()
-            if _ == 0:
-                for a, p in zip(g0, m.parameters()):
-                    assert torch.equal(a, p.grad)
-            opt.step()
-        torch.cuda.synchronize()
-        assert torch.isfinite(loss).item()
-        # several buckets, reduced behind the plan's second stream without joining the streams in between
-        assert len(m._dp.buckets_for(m.last_plan)) >= 2
-        assert getattr(m.last_plan, "side_stream", None) is not None
+        finals = {}
+        for mode in unet_amd.GradientReducer.MODES:      # one all-reduce per bucket / reduce-scatter + all-gather
+            torch.manual_seed(0)
+            m = unet_amd.UNet(12, 1, (8, 16, 32, 64), compute_dtype="fp32").cuda()
+            red = unet_amd.GradientReducer(bucket_bytes=64 << 10, force=True, mode=mode).attach(m)
+            assert m._dp is red and red.mode == mode
+            unet_amd.broadcast_parameters(m)
+            opt = unet_amd.FusedAdam(m.parameters(), lr=1e-4, model=m)
+            for _ in range(3):
+                loss = crit(m(X), Y)
+                opt.zero_grad()
+                loss.backward()
+                if _ == 0:
+                    for a, p in zip(g0, m.parameters()):
+                        assert torch.equal(a, p.grad), mode
+                opt.step()
+            torch.cuda.synchronize()
+            assert torch.isfinite(loss).item()
+            # several buckets, reduced behind the plan's second stream without joining the streams in between
+            assert len(m._dp.buckets_for(m.last_plan)) >= 2
+            assert getattr(m.last_plan, "side_stream", None) is not None
+            finals[mode] = [p.detach().clone() for p in m.parameters()]
+        for a, b in zip(finals["allreduce"], finals["rs_ag"]):       # one rank: both leave the gradients as they were
+            assert torch.equal(a, b)
         monkeypatch.setenv("UNET_TM_GRAPH", "1")
         torch.manual_seed(0)
         mg = unet_amd.UNet(12, 1, (8, 16, 32, 64), compute_dtype="fp32").cuda()
@@ -673,3 +681,214 @@ def test_captured_launch_graphs_give_identical_results(monkeypatch):
         assert torch.equal(p0, p1)
         for a, b in zip(g0, g1):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+@pytest.mark.parametrize("bucket_bytes", [1, 64 << 10, 1 << 30])
+def test_dp_ordering_with_a_late_collective_that_changes_the_data(monkeypatch, graph, bucket_bytes):
+    """An all-reduce in a one-rank group is the identity, so it cannot show a collective that runs before
+    its bucket's weight gradients are final, or an optimizer that reads a bucket before its collective is
+    done.  Here the collective's stand-in is LATE and CHANGES the data: on the stream that is current at
+    the call it first runs >= 50 us of unrelated GPU work, then doubles the slice in place.
+      * every p.grad the optimizer sees must be exactly twice the gradient of a run without data
+        parallelism (a collective enqueued ahead of a producer would double stale data, which the
+        producer then overwrites: 1x; a doubled partial result: anything else);
+      * the parameters after FusedAdam.step() must equal, bit for bit, those of a run that was handed
+        2*g directly (an optimizer that did not wait for the last collective would have used 1*g)."""
+    import unet_amd
+    monkeypatch.setenv("UNET_TM_GRAPH", graph)
+    feats = (8, 16, 32, 64)
+    X, Y = (t.cuda() for t in O.synthetic_batch(8, 12, 1, 32, 32))
+    crit = unet_amd.MSELoss()
+    busy_a = torch.randn(2048, 2048, device="cuda")
+    busy_b = torch.empty_like(busy_a)
+
+    class LateDoubler(unet_amd.GradientReducer):
+        calls = 0
+
+        def reduce_async(self, t):
+            torch.mm(busy_a, busy_a, out=busy_b)      # 17 GFLOP of fp32: well over 50 us in front of the change
+            t.mul_(2.0)
+            LateDoubler.calls += 1
+
+        def wait_all(self):
+            pass
+
+    def run(dp, steps=4):
+        torch.manual_seed(0)
+        m = unet_amd.UNet(12, 1, feats, compute_dtype="bf16").cuda()
+        opt = unet_amd.FusedAdam(m.parameters(), lr=1e-3, model=m)
+        if dp:
+            red = LateDoubler(bucket_bytes=bucket_bytes)
+            red.force = True
+            red.attach(m)
+            assert m._dp is red
+        seen = []
+        for _ in range(steps):               # with graphs on, the launch sequences replay from the third step
+            loss = crit(m(X), Y)
+            opt.zero_grad()
+            loss.backward()
+            if not dp:
+                for p in m.parameters():
+                    p.grad.mul_(2.0)
+            seen.append([p.grad.clone() for p in m.parameters()])
+            opt.step()
+        torch.cuda.synchronize()
+        return seen, [p.detach().clone() for p in m.parameters()], m
+
+    # timing of the stand-in: the delay in front of the data change is what makes a missing wait visible
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.mm(busy_a, busy_a, out=busy_b)
+    e0.record(); torch.mm(busy_a, busy_a, out=busy_b); e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) >= 0.05
+
+    ref_grads, ref_params, _ = run(dp=False)
+    LateDoubler.calls = 0
+    got_grads, got_params, m = run(dp=True)
+    n_buckets = len(m._dp.buckets_for(m.last_plan))
+    assert LateDoubler.calls == 4 * n_buckets
+    assert n_buckets == (10 if bucket_bytes == 1 else 1 if bucket_bytes == 1 << 30 else n_buckets) and n_buckets >= 1
+    for step, (gs, rs) in enumerate(zip(got_grads, ref_grads)):
+        for i, (a, b) in enumerate(zip(gs, rs)):
+            assert torch.equal(a, b), (step, i)
+    for a, b in zip(got_params, ref_params):
+        assert torch.equal(a, b)
+
+
+def test_full_size_properties_of_the_deep_configuration(golden):
+    """The 5-level 24 -> 12 channel network on 128x128 matrices at the batch the benchmark runs it with
+    (64), bf16: bitwise run-to-run determinism, finite gradients, batch additivity (two halves of 32
+    against the 64), and the first two rows predicted as a batch of two predicts them -- whose norm the
+    reference recorded (cfg4_b2: the same two inputs)."""
+    import unet_amd
+    g = golden("cfg4_b2")
+    cin, cout, feats, _ = meta(g)
+    assert (cin, cout, len(feats)) == (24, 12, 5)
+    torch.manual_seed(0)
+    model = unet_amd.UNet(cin, cout, feats, compute_dtype="bf16").to("cuda")
+    X, Y = O.synthetic_batch(64, cin, cout, 128, 128)
+    X, Y = X.cuda(), Y.cuda()
+    crit = unet_amd.MSELoss()
+
+    def grads(xb, yb):
+        model.zero_grad(set_to_none=True)
+        pred = model(xb)
+        loss = crit(pred, yb)
+        loss.backward()
+        return loss.detach(), pred.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+
+    l1, p1, g1 = grads(X, Y)
+    l2, p2, g2 = grads(X, Y)
+    assert torch.equal(l1, l2) and torch.equal(p1, p2) and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and torch.isfinite(p1).all()
+    _, _, ga = grads(X[:32], Y[:32])
+    _, _, gb = grads(X[32:], Y[32:])
+    assert rel(0.5 * (ga + gb), g1) < 2e-2
+    # rows 0-1 as a batch of their own (other kernels are picked at that size): same prediction to bf16
+    # rounding, and the norm the reference computed for exactly these two inputs
+    with torch.no_grad():
+        p_two = model(X[:2]).clone()
+    assert rel(p1[:2], p_two) < BAR["bf16"]["out"]
+    assert abs(p1[:2].double().norm().item() - float(g["prednorm"])) <= BAR["bf16"]["out"] * float(g["prednorm"])
+    pv = p1[:2].cpu().flatten()[torch.from_numpy(g["predidx"])]
+    assert rel(pv, torch.from_numpy(g["predval"])) < 3 * BAR["bf16"]["out"]
+    # the loss of those two rows against the targets the fixture's run used (drawn right after ITS two inputs)
+    _, Y2 = O.synthetic_batch(2, cin, cout, 128, 128)
+    loss2 = crit(p1[:2].contiguous(), Y2.cuda())
+    assert abs(loss2.item() - float(g["loss0"])) <= BAR["bf16"]["out"] * float(g["loss0"])
+    del model
+    torch.cuda.empty_cache()
+
+
+# Loss-curve bars of the long run: deviations grow with the number of steps (every step's rounding
+# differences feed the next), so they are looser than the 20-step bars above.
+CURVE_BAR = {"fp32": 2e-3, "bf16": 5e-2}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_long_loss_curve_tracks_the_reference(ua, golden, dtype):
+    """240 Adam steps at lr 1e-3 over four batches in rotation, recorded from the reference (the loss falls
+    13-fold): every step's loss within the bar of the reference's, and the run must really have learned."""
+    from conftest import curve_batches
+    g = golden("curve240")
+    cin, cout, feats, _ = meta(g)
+    batches = [(X.cuda(), Y.cuda()) for X, Y in curve_batches(g)]
+    torch.manual_seed(0)
+    model = ua.UNet(cin, cout, feats, compute_dtype=dtype).to("cuda")
+    opt = ua.FusedAdam(model.parameters(), lr=float(g["meta.lr"]), model=model)
+    crit = ua.MSELoss()
+    losses = []
+    model.train()
+    for s in range(len(g["losses"])):
+        X, Y = batches[s % len(batches)]
+        loss = crit(model(X), Y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    losses = torch.stack(losses).cpu().double().numpy()
+    ref = np.asarray(g["losses"])
+    dev = np.abs(losses - ref) / np.abs(ref)
+    print(f"curve240[{dtype}]: max rel dev {dev.max():.3e} at step {dev.argmax()}, mean {dev.mean():.3e}, "
+          f"final {losses[-1]:.5f} vs {ref[-1]:.5f}")
+    assert dev.max() < CURVE_BAR[dtype], (dev.max(), int(dev.argmax()))
+    assert losses[-1] < 0.1 * losses[0]
+    model.eval()
+    a = s2 = 0.0
+    with torch.no_grad():
+        for X, Y in batches:
+            sums, _ = ua.eval_sums(model(X), Y)
+            a += sums[0].item(); s2 += sums[1].item()
+    assert abs(a - float(g["eval.abs_sum"])) <= CURVE_BAR[dtype] * float(g["eval.abs_sum"])
+    assert abs(s2 - float(g["eval.sq_sum"])) <= 2 * CURVE_BAR[dtype] * float(g["eval.sq_sum"])
+
+
+def test_k_split_across_workgroups_is_repeatable_and_leaves_its_counters_at_zero(ua):
+    """Few-pixel layers with K >= 4096 (default widths, one 64x64 matrix: the bottleneck's second conv and
+    the first decoder conv) split K across workgroups and exchange partial tiles through workspace scratch.
+    One workspace is driven through alternating inputs and weights: the same (input, weights) must predict
+    the same bits every time (a stale partial tile or a miscounted ticket would not), the split must agree
+    with the unsplit kernel to fp32 summation order, and the arrival counters must read zero between launches."""
+    import ctypes as C
+    from unet_amd._lib import MI_OPT_NO_KSPLIT
+    L = ua.lib()
+    state = O.init_state_dict(12, 1, (32, 64, 128, 256), seed=0)
+    model = ua.UNet(12, 1, (32, 64, 128, 256), compute_dtype="bf16")
+    model.load_state_dict(state)
+    model = model.to("cuda").eval()
+    Xs = [O.synthetic_batch(b, 12, 1, 64, 64, seed=20 + i)[0].cuda() for i, b in enumerate((1, 1, 2))]
+
+    def counters(plan):
+        off, cb, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        assert L.mi_unet_plan_ksplit_region(plan.handle, C.byref(off), C.byref(cb), C.byref(tot)) == 0
+        assert tot.value > cb.value > 0, "this shape was expected to carry K-split scratch"
+        return plan.ws[off.value: off.value + cb.value]
+
+    first = {}
+    with torch.no_grad():
+        for rnd in range(4):
+            for i, X in enumerate(Xs):
+                for scale in (1.0, 1.25):
+                    if scale != 1.0:
+                        model.bottleneck[2].weight.mul_(scale)
+                    pred = model(X).clone()
+                    assert int(counters(model.last_plan).to(torch.int32).abs().sum().item()) == 0
+                    if scale != 1.0:
+                        model.bottleneck[2].weight.div_(scale)      # 1.25 = 5/4: the division restores the bits
+                    key = (i, scale)
+                    if key in first:
+                        assert torch.equal(pred, first[key]), (rnd, key)
+                    else:
+                        first[key] = pred
+        assert not torch.equal(first[(0, 1.0)], first[(0, 1.25)]) and not torch.equal(first[(0, 1.0)], first[(1, 1.0)])
+        # the unsplit kernel on a plan of its own: same sums in another order
+        other = ua.UNet(12, 1, (32, 64, 128, 256), compute_dtype="bf16")
+        other.load_state_dict(state)
+        other = other.to("cuda").eval()
+        other(Xs[0])
+        assert L.mi_unet_plan_set_option(other.last_plan.handle, MI_OPT_NO_KSPLIT, 1) == 0
+        for i, X in enumerate(Xs[:2]):
+            assert rel(other(X), first[(i, 1.0)]) < 2e-3, i
+    ref = O.unet_forward(state, Xs[0].cpu())
+    assert rel(first[(0, 1.0)].cpu(), ref) < BAR["bf16"]["out"]

@@ -76,6 +76,25 @@ def test_adam_loss_curve_bit_identical(golden, name):
         assert (a, s, cnt) == (float(g["eval.abs_sum"]), float(g["eval.sq_sum"]), int(g["eval.numel"]))
 
 
+def test_long_loss_curve_bit_identical(golden):
+    """240 Adam steps at lr 1e-3 over four batches in rotation (the loss falls 13-fold): the oracle's loop
+    reproduces every loss the reference recorded, and the final test sums."""
+    from conftest import curve_batches
+    g = golden("curve240")
+    cin, cout, feats, _ = _meta(g)
+    batches = curve_batches(g)
+    n = len(g["losses"])
+    state = O.init_state_dict(cin, cout, feats, seed=0)
+    losses, final = O.train_steps(state, [batches[s % len(batches)] for s in range(n)], lr=float(g["meta.lr"]))
+    assert losses == [float(v) for v in g["losses"]]
+    assert losses[-1] < 0.1 * losses[0]
+    a = s = 0.0
+    for X, Y in batches:
+        ai, si, _ = O.eval_sums(final, X, Y)
+        a += ai; s += si
+    assert (a, s) == (float(g["eval.abs_sum"]), float(g["eval.sq_sum"]))
+
+
 @pytest.mark.parametrize("name", ["cfg1_full", "cfg2_b32"])
 def test_full_width_scalars(golden, name):
     g = golden(name)

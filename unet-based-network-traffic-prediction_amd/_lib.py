@@ -10,6 +10,7 @@ import os
 
 MI_F32, MI_BF16 = 0, 1
 MI_FWD_REPACK, MI_FWD_TRAIN = 1, 2
+MI_OPT_GRAPH, MI_OPT_SERIAL_BACKWARD, MI_OPT_DEBUG_STREAMS, MI_OPT_PACK_ONE_STREAM, MI_OPT_NO_KSPLIT = 1, 2, 3, 4, 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunet_tm_hip.so")
@@ -73,6 +74,8 @@ SIGNATURES = {
     "mi_unet_plan_segment_range": (_i, [_p, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "mi_unet_forward": (_i, [_p, _p, _p, _p, _sz, _p, _i, _p]),
     "mi_unet_backward": (_i, [_p, _p, _p, _p, _sz, _p, _f, _f, _i, _i, _p, _p]),
+    "mi_unet_plan_set_option": (_i, [_p, _i, _i]),
+    "mi_unet_plan_ksplit_region": (_i, [_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     "mi_unet_plan_defer_join": (_i, [_p, _i]),
     "mi_unet_plan_side_stream": (_p, [_p, _p]),
     "mi_unet_plan_last_call_deferred": (_i, [_p]),

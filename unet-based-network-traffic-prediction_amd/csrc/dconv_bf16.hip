@@ -24,8 +24,6 @@
 //     drain them).
 #include "hconv_impl.h"
 
-#include <cstdlib>
-
 namespace mi {
 
 constexpr int kDconvLds = 160 * 1024;
@@ -471,15 +469,9 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #endif
 }
 
-static bool dconv_disabled() {
-  static const bool off = [] { const char* e = getenv("UNET_TM_HCONV_REGS"); return e && e[0] == '1'; }();
-  return off;
-}
-
 // Launches the DMA-fed kernel when the layer suits it; returns -1000 when the caller should use
-// the register-staged kernel instead (an unsuitable shape, or UNET_TM_HCONV_REGS=1).
+// the register-staged kernel instead (an unsuitable shape).
 int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name) {
-  if (dconv_disabled()) return -1000;
   DconvArgs d{};
   d.h = a_in;
   HconvArgs& a = d.h;

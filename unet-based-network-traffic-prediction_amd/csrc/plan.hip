@@ -18,7 +18,6 @@
 // multiplied by the ReLU mask (i.e. they are gradients w.r.t. the conv's pre-activation).
 #include "common.h"
 
-#include <cstdlib>
 #include <cstring>
 #include <cstdio>
 #include <functional>
@@ -93,7 +92,12 @@ struct mi_unet_plan {
   struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; int state; };  // state 0 seen once, 1 ready, -1 unusable
   std::vector<GraphEntry> graphs;
   hipStream_t cap_stream;
-  int graph_mode;              // -1 not read yet, 0 off, 1 on
+  int graph_mode;              // MI_OPT_GRAPH: 0 off (default), 1 on
+  bool serial_backward;        // MI_OPT_SERIAL_BACKWARD: everything on the caller's stream
+  bool debug_streams;          // MI_OPT_DEBUG_STREAMS: report the side-stream choice on stderr
+  bool pack_one_stream;        // MI_OPT_PACK_ONE_STREAM: pack the dgrad weight images on the caller's stream too
+  bool no_ksplit;              // MI_OPT_NO_KSPLIT: the few-pixel conv kernel never splits K across workgroups
+  std::vector<const void*> known_ws;   // workspaces a forward with MI_FWD_REPACK has initialised (packed weights, zeroed counters)
   // second stream for the weight-gradient kernels of a backward call (see fork_side)
   hipStream_t side;
   bool side_tried, side_busy;
@@ -188,7 +192,7 @@ double esz(const mi_unet_plan* P) { return (double)elem_size(P->d.dtype); }
 // (the producer of dy) and returns it; join_side() at the end of the call makes the caller's
 // stream wait for the side stream, so in the caller's stream order the whole call is complete.
 // Per-launch profiling keeps everything on one stream (the timings must not overlap), and so
-// does UNET_TM_SERIAL_BACKWARD=1.
+// does the plan option MI_OPT_SERIAL_BACKWARD.
 hipEvent_t next_sync_event(mi_unet_plan* P) {
   if (P->sync_used == P->sync_pool.size()) {
     hipEvent_t e;
@@ -216,7 +220,7 @@ __global__ void noop_kernel() {}
 // not before, so that a later candidate is never handed the slot of an earlier one.
 static std::mutex g_side_mutex;
 static std::map<std::pair<int, hipStream_t>, hipStream_t> g_side_choice;
-static hipStream_t choose_side_stream(hipStream_t main) {
+static hipStream_t choose_side_stream(hipStream_t main, bool debug) {
   constexpr int kCandidates = 8;
   hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
   hipStream_t chosen = nullptr;
@@ -244,14 +248,13 @@ static hipStream_t choose_side_stream(hipStream_t main) {
   if (e0) (void)hipEventDestroy(e0);
   if (ea) (void)hipEventDestroy(ea);
   if (eb) (void)hipEventDestroy(eb);
-  if (getenv("UNET_TM_DEBUG_STREAMS")) fprintf(stderr, "[unet_tm] side stream: %s after %d candidates\n", chosen ? "found" : "none", tried);
+  if (debug) fprintf(stderr, "[unet_tm] side stream: %s after %d candidates\n", chosen ? "found" : "none", tried);
   return chosen;
 }
 static void ensure_side(mi_unet_plan* P, hipStream_t main) {
   if (P->side_tried) return;
   P->side_tried = true;
-  const char* env = getenv("UNET_TM_SERIAL_BACKWARD");
-  if (env && env[0] == '1') return;
+  if (P->serial_backward) return;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return;
   std::lock_guard<std::mutex> lock(g_side_mutex);
@@ -266,7 +269,7 @@ static void ensure_side(mi_unet_plan* P, hipStream_t main) {
     P->side_owned = true;
     return;
   }
-  P->side = choose_side_stream(main);
+  P->side = choose_side_stream(main, P->debug_streams);
   g_side_choice[key] = P->side;
 }
 hipStream_t fork_side(Run& r) {
@@ -285,9 +288,9 @@ int join_side(Run& r) {
   P->side_busy = false;
   hipEvent_t e = next_sync_event(P);
   P->sync_used = 0;   // a wait refers to its event's record at the time of the call: the next call reuses the pool
-  if (!e) return fail(MI_ESTATE, "unet_backward: cannot create an event");
-  int rc = check_hip(hipEventRecord(e, P->side), "unet_backward: event record");
-  if (rc == MI_OK) rc = check_hip(hipStreamWaitEvent(r.s, e, 0), "unet_backward: stream wait");
+  if (!e) return fail(MI_ESTATE, "joining the second stream: cannot create an event");
+  int rc = check_hip(hipEventRecord(e, P->side), "joining the second stream: event record");
+  if (rc == MI_OK) rc = check_hip(hipStreamWaitEvent(r.s, e, 0), "joining the second stream: stream wait");
   return rc;
 }
 
@@ -319,7 +322,7 @@ int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, con
   IgemmArgs a = conv3x3_fwd_args(x.p, x.cs, x.co, r.ws + l.wf_off, r.Bv(l), y.p, y.cs, y.co, B, H, W, l.cin, l.split,
                                  l.cout, 1);
   if (pool) { a.pool = pool->p; a.pool_cs = pool->cs; a.pool_co = pool->co; }
-  if (r.P->ksplit_bytes) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
+  if (r.P->ksplit_bytes && !r.P->no_ksplit) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
   return rc;
@@ -331,7 +334,7 @@ int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, in
   const char* k = nullptr;
   IgemmArgs a = conv3x3_dgrad_args(dy.p, dy.cs, dy.co, r.ws + l.wb_off, dx.p, dx.cs, dx.co, mask ? mask->p : nullptr,
                                    mask ? mask->cs : 0, mask ? mask->co : 0, B, H, W, l.cin, l.split, l.cout);
-  if (r.P->ksplit_bytes) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
+  if (r.P->ksplit_bytes && !r.P->no_ksplit) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
   return rc;
@@ -413,17 +416,13 @@ int flush_wgrads(Run& r, int seg) {
 // the graph, so new batches never invalidate it.  Capture runs on a private stream (the caller's
 // may be the legacy default stream, which cannot capture); the side stream of the wgrad kernels
 // joins the capture through its fork/join events.
-// Off by default, UNET_TM_GRAPH=1 turns it on: measured on MI355X (batch 512, 32x32) the step is
+// Off by default, the plan option MI_OPT_GRAPH turns it on: measured on MI355X (batch 512, 32x32) the step is
 // GPU-bound, replay is no faster than eager launches on one stream (1.81 ms either way), and a
 // graph loses the overlap the eager two-stream backward gets (1.83 ms against 1.70 ms).  It pays
 // only where the host cannot keep ahead (small batches, slow hosts).
 constexpr size_t kMaxGraphs = 12;
 template <typename Body>
 int run_graphed(mi_unet_plan* P, const std::vector<uint64_t>& key, hipStream_t stream, Body body) {
-  if (P->graph_mode < 0) {
-    const char* env = getenv("UNET_TM_GRAPH");
-    P->graph_mode = (env && env[0] == '1') ? 1 : 0;
-  }
   if (P->profile || P->graph_mode == 0) return body(stream);
   mi_unet_plan::GraphEntry* e = nullptr;
   for (auto& g : P->graphs)
@@ -496,7 +495,8 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   P->profile = false;
   P->events_used = 0;
   P->side = nullptr; P->side_tried = false; P->side_busy = false; P->sync_used = 0; P->defer_join = false; P->side_owned = false; P->last_deferred = false;
-  P->cap_stream = nullptr; P->graph_mode = -1;
+  P->cap_stream = nullptr; P->graph_mode = 0;
+  P->serial_backward = false; P->debug_streams = false; P->pack_one_stream = false; P->no_ksplit = false;
   P->h.resize(L + 1); P->w.resize(L + 1);
   P->h[0] = d.height; P->w[0] = d.width;
   for (int l = 0; l < L; ++l) { P->h[l + 1] = P->h[l] / 2; P->w[l + 1] = P->w[l] / 2; }
@@ -754,19 +754,10 @@ int mi_unet_profile_read(mi_unet_plan* plan, int i, char* kernel, int kcap, char
 namespace {
 // phases: PH_IN = input layout (reads x_nchw), PH_BODY = everything on plan-owned memory,
 // PH_OUT = head and forced output resize (write pred_nchw)
-int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_flat, void* ws, float* pred_nchw,
-                   int flags, hipStream_t stream, int phases) {
+int forward_body(Run& r, int flags) {
+  mi_unet_plan* P = r.P;
   const mi_unet_desc& d = P->d;
   const int L = P->L, B = d.batch, dt = d.dtype;
-  Run r{P, (char*)ws, params_flat, stream, 0};
-
-  if (phases & PH_IN) {
-    Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
-    sc.kernel("nchw_to_nhwc");
-    View x = r.view("x");
-    RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
-  }
-  if (phases & PH_BODY) {
   if (flags & MI_FWD_REPACK) {
     const bool train = (flags & MI_FWD_TRAIN) != 0;
     Scope sc(P, r.s, "pack_weights", 0, 0);
@@ -777,8 +768,7 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     // The forward images are needed at once; the backward images (dgrad operands) not before the
     // backward pass: in training they are packed on the second stream, which has nothing else to do
     // during a forward pass, and joined at the end of this call.
-    static const bool one_stream = getenv("UNET_TM_PACK_ONE_STREAM") != nullptr;
-    hipStream_t bs = train && !one_stream ? fork_side(r) : r.s;
+    hipStream_t bs = train && !P->pack_one_stream ? fork_side(r) : r.s;
     for (int pass = 0; pass < (train ? 2 : 1); ++pass) {
       hipStream_t ps = pass == 0 ? r.s : bs;
       PackJobs J;
@@ -854,8 +844,29 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     RUN(do_conv_fwd(r, c2, u1, u2, B, P->h[l], P->w[l], c2.prefix.c_str()));
     cur = u2;
   }
-  RUN(join_side(r));      // the backward images, if they were packed beside this pass
-  }  // PH_BODY
+  return MI_OK;
+}
+
+int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_flat, void* ws, float* pred_nchw,
+                   int flags, hipStream_t stream, int phases) {
+  const mi_unet_desc& d = P->d;
+  const int L = P->L, B = d.batch, dt = d.dtype;
+  Run r{P, (char*)ws, params_flat, stream, 0};
+
+  if (phases & PH_IN) {
+    Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
+    sc.kernel("nchw_to_nhwc");
+    View x = r.view("x");
+    RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
+  }
+  if (phases & PH_BODY) {
+    // Whatever way the body ends, the second stream (the backward weight images, if they were packed
+    // beside this pass) is joined: an error half-way must not leave a fork dangling for the next call.
+    const int rc = forward_body(r, flags);
+    const int rj = join_side(r);
+    if (rc != MI_OK) return rc;
+    RUN(rj);
+  }
   if (phases & PH_OUT) {
     const Layer& hd = P->layers.back();
     View cur = r.view("u2." + std::to_string(L - 1));
@@ -887,6 +898,18 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
   if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_forward: workspace too small");
   MI_REQUIRE(((uintptr_t)ws & 255) == 0 && ((uintptr_t)params_flat & 15) == 0, "unet_forward: workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  // A workspace carries state between calls (packed weights; counters the few-pixel conv kernel expects at
+  // zero).  Only a forward with MI_FWD_REPACK creates it: without the flag an unknown workspace is refused,
+  // because the kernels would neither fault nor complain, they would write no output at all.
+  bool known = false;
+  for (const void* k : P->known_ws) known = known || k == ws;
+  if (!known) {
+    if (!(flags & MI_FWD_REPACK))
+      return fail(MI_ESTATE, "unet_forward: the first forward on a workspace must carry MI_FWD_REPACK (it packs the weights and "
+                             "zeroes the workspace's counters)");
+    if (P->known_ws.size() >= 64) P->known_ws.erase(P->known_ws.begin());
+    P->known_ws.push_back(ws);
+  }
   if (P->profile) { P->prof.clear(); P->events_used = 0; }
   RUN(forward_phases(P, x_nchw, params_flat, ws, pred_nchw, flags, s, PH_IN));
   const std::vector<uint64_t> key = {1u, (uint64_t)(uintptr_t)params_flat, (uint64_t)(uintptr_t)ws, (uint64_t)flags};
@@ -903,11 +926,11 @@ int mi_unet_forward(mi_unet_plan* P, const float* x_nchw, const float* params_fl
 namespace {
 // phases: PH_IN = segment 0, the head (reads dpred_nchw), PH_BODY = the other segments,
 // PH_OUT = layout change of the input gradient (writes dx_nchw)
-int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* params_flat, void* ws, float* grads,
-                    float alpha, float beta, int seg_lo, int seg_hi, float* dx_nchw, hipStream_t stream, int phases) {
+int backward_segments(Run& r, const float* dpred_nchw, float* grads, float alpha, float beta, int seg_lo, int seg_hi,
+                      float* dx_nchw, int phases) {
+  mi_unet_plan* P = r.P;
   const mi_unet_desc& d = P->d;
   const int L = P->L, B = d.batch, dt = d.dtype;
-  Run r{P, (char*)ws, params_flat, stream, 0};
 
   for (int seg = seg_lo; seg < seg_hi; ++seg) {
     const int seg_phases = seg == 0 ? PH_IN : (seg >= L + 2 ? PH_BODY | PH_OUT : PH_BODY);
@@ -1039,6 +1062,18 @@ int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* param
     }
     RUN(flush_wgrads(r, seg));
   }
+  return MI_OK;
+}
+
+int backward_phases(mi_unet_plan* P, const float* dpred_nchw, const float* params_flat, void* ws, float* grads,
+                    float alpha, float beta, int seg_lo, int seg_hi, float* dx_nchw, hipStream_t stream, int phases) {
+  Run r{P, (char*)ws, params_flat, stream, 0};
+  const int rc = backward_segments(r, dpred_nchw, grads, alpha, beta, seg_lo, seg_hi, dx_nchw, phases);
+  if (rc != MI_OK) {           // an error half-way: leave no fork dangling and no queued job behind
+    r.wjobs.clear(); r.deferred.clear();
+    (void)join_side(r);
+    return rc;
+  }
   if (!(phases & PH_BODY)) return MI_OK;
   if (defer_to_side(r, seg_hi)) return MI_OK;
   return join_side(r);
@@ -1052,6 +1087,11 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
   MI_REQUIRE(P && dpred_nchw && params_flat && ws && grads, "unet_backward: null pointer");
   if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_backward: workspace too small");
   if (!P->forward_done) return fail(MI_ESTATE, "unet_backward: no forward pass has been run on this plan");
+  {
+    bool known = false;
+    for (const void* k : P->known_ws) known = known || k == ws;
+    if (!known) return fail(MI_ESTATE, "unet_backward: no forward pass has been run on this workspace");
+  }
   const int nseg = (int)P->segs.size();
   MI_REQUIRE(seg_lo >= 0 && seg_hi <= nseg && seg_lo <= seg_hi, "unet_backward: bad segment range");
   MI_REQUIRE(!P->d.need_input_grad || dx_nchw || seg_hi < nseg, "unet_backward: dx buffer required");
@@ -1075,6 +1115,35 @@ int mi_unet_backward(mi_unet_plan* P, const float* dpred_nchw, const float* para
   return MI_OK;
 }
 
+int mi_unet_plan_set_option(mi_unet_plan* P, int option, int value) {
+  MI_REQUIRE(P, "unet_plan_set_option: null plan");
+  switch (option) {
+    case MI_OPT_GRAPH:
+      if ((value != 0) != (P->graph_mode != 0)) {      // graphs captured under the other setting are dropped
+        for (auto& g : P->graphs)
+          if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        P->graphs.clear();
+      }
+      P->graph_mode = value != 0;
+      return MI_OK;
+    case MI_OPT_SERIAL_BACKWARD:
+      MI_REQUIRE(!P->side_tried || P->serial_backward == (value != 0),
+                 "unet_plan_set_option: MI_OPT_SERIAL_BACKWARD must be set before the plan's first training call");
+      P->serial_backward = value != 0;
+      return MI_OK;
+    case MI_OPT_DEBUG_STREAMS: P->debug_streams = value != 0; return MI_OK;
+    case MI_OPT_PACK_ONE_STREAM: P->pack_one_stream = value != 0; return MI_OK;
+    case MI_OPT_NO_KSPLIT: P->no_ksplit = value != 0; return MI_OK;
+    default: return fail(MI_EINVAL, "unet_plan_set_option: unknown option");
+  }
+}
+int mi_unet_plan_ksplit_region(const mi_unet_plan* P, size_t* ws_offset_bytes, size_t* counter_bytes, size_t* total_bytes) {
+  MI_REQUIRE(P, "unet_plan_ksplit_region: null plan");
+  if (ws_offset_bytes) *ws_offset_bytes = P->ksplit_off;
+  if (counter_bytes) *counter_bytes = P->ksplit_bytes ? kKsplitCounterBytes : 0;
+  if (total_bytes) *total_bytes = P->ksplit_bytes;
+  return MI_OK;
+}
 int mi_unet_plan_defer_join(mi_unet_plan* P, int on) {
   MI_REQUIRE(P, "unet_plan_defer_join: null plan");
   P->defer_join = on != 0;

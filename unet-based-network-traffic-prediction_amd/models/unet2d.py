@@ -23,7 +23,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
-from .._lib import MI_FWD_REPACK, MI_FWD_TRAIN, UNetDesc, check, lib
+from .._lib import (MI_FWD_REPACK, MI_FWD_TRAIN, MI_OPT_DEBUG_STREAMS, MI_OPT_GRAPH, MI_OPT_PACK_ONE_STREAM,
+                    MI_OPT_SERIAL_BACKWARD, UNetDesc, check, lib)
 from ..ops import mi_dtype, torch_dtype
 
 # The reference trains and evaluates in fp32 with no autocast (train.py:495-498), so the drop-in default
@@ -66,7 +67,13 @@ class _Plan:
         # passes run on it; `leased` is the generation whose backward is still to come (None = free).
         self.generation = 0
         self.leased: Optional[int] = None
-        self.graph_mode = _graph_mode()
+        # The library reads no environment itself: the switches are plan options, set here.
+        self.graph_mode = _env_flag("UNET_TM_GRAPH")
+        for opt, on in ((MI_OPT_GRAPH, self.graph_mode), (MI_OPT_SERIAL_BACKWARD, _env_flag("UNET_TM_SERIAL_BACKWARD")),
+                        (MI_OPT_DEBUG_STREAMS, _env_flag("UNET_TM_DEBUG_STREAMS")),
+                        (MI_OPT_PACK_ONE_STREAM, _env_flag("UNET_TM_PACK_ONE_STREAM"))):
+            if on:
+                check(L.mi_unet_plan_set_option(handle, opt, 1), "plan_set_option")
 
     def tensors(self) -> Dict[str, dict]:
         """Named activation / gradient views inside the workspace (for parity checks)."""
@@ -89,9 +96,10 @@ class _Plan:
             pass
 
 
-def _graph_mode() -> bool:
-    env = os.environ.get("UNET_TM_GRAPH", "")
-    return env[:1] == "1"        # the library reads the variable the same way, once per plan
+def _env_flag(name: str) -> bool:
+    """Environment switch read when a plan is created (UNET_TM_GRAPH, UNET_TM_SERIAL_BACKWARD,
+    UNET_TM_DEBUG_STREAMS, UNET_TM_PACK_ONE_STREAM): "1" turns it on."""
+    return os.environ.get(name, "")[:1] == "1"
 
 
 class _Lease:
