@@ -223,7 +223,10 @@ def test_maxpool_bwd_bf16_even_images(ua, shape):
                                    # the 5-level network's first transposed conv (models/unet2d.py:46-48, 1024 -> 512)
                                    (2, 1024, 512, 4, 4), (64, 1024, 512, 4, 4),
                                    # >= 65536 pixels: the streaming kernel (weights in LDS), with a ragged last block
-                                   (67, 64, 32, 32, 31), (70, 128, 64, 31, 31), (66, 64, 24, 32, 32)])
+                                   (67, 64, 32, 32, 31), (70, 128, 64, 31, 31), (66, 64, 24, 32, 32),
+                                   # fewer pixel blocks than CUs / a weight matrix beyond 64 KB: the same kernel cut
+                                   # along the output channels (2 and 8 slices)
+                                   (33, 128, 64, 32, 31), (40, 256, 128, 16, 15)])
 def test_convt2x2(ua, dtype, shape):
     B, Cin, Cout, H, W = shape
     ops = ua.ops

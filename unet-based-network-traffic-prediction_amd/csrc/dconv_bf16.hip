@@ -223,9 +223,13 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     for (int s = 0; s < nstages; ++s) {
       // weight pieces first, pixel pieces after them: the counted wait below relies on that order
       const bool doW = !resident && s + 1 < nstages;
-      if (doW) issue_w(chunk + 1 == a.nchunks ? 0 : chunk + 1, (s + 1) & 1);
       const bool doA = lstage < nstages;             // the tile of stage s+NA-1 goes into the slot stage s-1 left
+#if defined(MI_DCONV_X_NODMA)
+      if (doA) advance_load();
+#else
+      if (doW) issue_w(chunk + 1 == a.nchunks ? 0 : chunk + 1, (s + 1) & 1);
       if (doA) { issue_a(ltile, lchunk, lslot); advance_load(); }
+#endif
       // Everything stage s+1 reads must have landed: its pixel tile and (streaming) its weights.
       // Only the pixel tiles of later stages may stay in flight: with resident weights those of
       // stages s+2 .. s+NA-1, with streamed weights (issued after them) only this stage's own issue.
@@ -233,6 +237,9 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       if (later < 0) later = 0;
       if (!resident && later > 1) later = 1;
       if (!resident && !doA) later = 0;
+#if defined(MI_DCONV_X_NODMA)
+      later = 0;
+#endif
       wait_vmcnt(later * cnt_a);
       __builtin_amdgcn_s_barrier();
       if (++chunk == a.nchunks) chunk = 0;
@@ -432,6 +439,26 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll
       for (int i = 0; i < TN; ++i) wf[set][i] = *(const frag_t*)(Wb + tap * BN * 64 + wfrag[i]);
     };
+#if defined(MI_DCONV_X_NOREAD)
+    read_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = mma_slab(wf[0][i], pf[0][j], acc[i][j]);
+    }
+#elif defined(MI_DCONV_X_NOMFMA)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      read_tap(tap, tap & 1);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(pf[tap & 1][j]));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(wf[tap & 1][i]));
+    }
+    acc[0][0] = mma_slab(wf[0][0], pf[0][0], acc[0][0]);
+#else
     read_tap(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -441,6 +468,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = mma_slab(wf[tap & 1][i], pf[tap & 1][j], acc[i][j]);
     }
+#endif
 #ifdef MI_DCONV_DIAG
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
 #endif

@@ -271,7 +271,13 @@ template <typename T, int WM, int WN, int TM, int TN, int MODE>
 static int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   dim3 grid((a.M + BM - 1) / BM, a.N / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, 2, MODE>), grid, dim3(256), 0, s, a);
+  // A K loop iteration is one memory round trip: the transposed convs of the deep levels (64x64 tiles,
+  // K of 512 and up) take 128 k per iteration instead of 64, half as many round trips.
+  constexpr bool deep = MODE != G_3x3 && BM == 64 && BN == 64 && sizeof(T) == 2;
+  if (deep && a.Kp % 128 == 0 && a.taps * a.Cin >= 512)
+    hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, deep ? 4 : 2, MODE>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, 2, MODE>), grid, dim3(256), 0, s, a);
   return check_hip(hipGetLastError(), "igemm launch");
 }
 
