@@ -27,7 +27,7 @@ int launch_igemm_f32(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
-int launch_dconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
+int launch_dconv_bf16(const HconvArgs& a, hipStream_t s, const char** name, bool dry_run = false);
 bool sconv_applies(const IgemmArgs& a);
 int launch_sconv_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
@@ -82,6 +82,35 @@ static int static_scratch(void** out) {
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// The halo-tile geometry of a 3x3 layer, or false when the layer does not tile into 256-pixel blocks.
+static bool hconv_args_for(const IgemmArgs& a, int dtype, HconvArgs* out) {
+  if (!(a.mode == G_3x3 && a.epi != E_SHUFFLE_BIAS && a.M % 256 == 0 && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
+  const int ck = dtype == MI_BF16 ? 32 : 16;
+  int R, G, bands;
+  if (!(a.Cin % ck == 0 && hconv_tiling(a.Hi, a.Wi, &R, &G, &bands) && (G == 1 || a.B % G == 0))) return false;
+  HconvArgs h{};
+  h.in = a.in; h.in_cs = a.in_cs; h.in_co = a.in_co;
+  h.w = a.w; h.Kp = a.Kp; h.Cp = a.Cin;
+  h.N = a.N; h.bias = a.epi == E_PLAIN ? nullptr : a.bias; h.n_real = a.n_real; h.relu = a.epi == E_BIAS_RELU;
+  h.out = a.out; h.out_cs = a.out_cs; h.out_co = a.out_co;
+  h.mask = a.mask; h.mask_cs = a.mask_cs; h.mask_co = a.mask_co;
+  h.pool = a.pool; h.pool_cs = a.pool_cs; h.pool_co = a.pool_co;
+  h.W = a.Wi; h.R = R; h.G = G; h.pitch = (a.Wi + 2 + 7) / 8 * 8; h.HR = G * (R + 2) * h.pitch; h.bands = bands;
+  h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
+  h.in2 = a.in2; h.chunk2 = a.in2_c0 / ck; h.out2 = a.out2; h.n2 = a.out2_n0;
+  *out = h;
+  return true;
+}
+// Whether a bf16 3x3 layer (forward or dgrad arguments) runs on the DMA-fed halo-tile kernel: the one kernel
+// that takes two-tensor operands (IgemmArgs::in2 / out2).  Mirrors the dispatch of launch_igemm.
+bool conv3x3_takes_dconv(const IgemmArgs& a, int dtype) {
+  if (dtype != MI_BF16 || sconv_applies(a)) return false;
+  HconvArgs h{};
+  if (!hconv_args_for(a, dtype, &h)) return false;
+  if (a.pool != nullptr && !(a.mask == nullptr && a.Hi % 2 == 0 && a.Wi % 2 == 0 && h.R % 2 == 0)) return false;
+  return launch_dconv_bf16(h, nullptr, nullptr, true) == MI_OK;
+}
+
 int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** name) {
   IgemmArgs a = a_in;
   a.zero = zero_page();
@@ -98,36 +127,35 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
              "igemm: pointers must be 16-byte aligned");
   MI_REQUIRE(a.epi == E_PLAIN || a.bias != nullptr, "igemm: bias required by this epilogue");
   MI_REQUIRE(a.epi != E_SHUFFLE_BIAS || (a.shufC % 16 == 0 && a.N == 4 * a.shufC), "igemm: bad shuffle width");
-  MI_REQUIRE(a.in_co + a.Cin <= a.in_cs, "igemm: input channel range exceeds the view stride");
+  MI_REQUIRE(a.in2 != nullptr ? (a.in_co + a.in2_c0 <= a.in_cs && a.Cin - a.in2_c0 <= a.in_cs && a.in2_c0 > 0 && a.in2_c0 < a.Cin)
+                              : a.in_co + a.Cin <= a.in_cs,
+             "igemm: input channel range exceeds the view stride");
+  MI_REQUIRE(a.out2 == nullptr || (a.out2_n0 > 0 && a.out2_n0 < a.N && a.out_co + a.out2_n0 <= a.out_cs && a.N - a.out2_n0 <= a.out_cs),
+             "igemm: output channel range exceeds the view stride");
+  const bool two_tensors = a.in2 != nullptr || a.out2 != nullptr;
+  MI_REQUIRE(!two_tensors || (dtype == MI_BF16 && a.in2_c0 % 32 == 0 && a.out2_n0 % 16 == 0 && aligned16(a.in2) && aligned16(a.out2)),
+             "igemm: two-tensor operands need bf16 and 32-channel-aligned halves");
   // 3x3 layers of so few pixels that a pixel-tiled kernel would leave most CUs idle: K-split kernel
-  if (dtype == MI_BF16 && sconv_applies(a)) return launch_sconv_bf16(a, s, name);
+  if (dtype == MI_BF16 && !two_tensors && sconv_applies(a)) return launch_sconv_bf16(a, s, name);
   // 3x3 stride-1 convolutions whose images tile evenly into 256-pixel blocks take the halo-tile
   // kernel (one LDS halo tile serves all 9 taps); everything else the generic gather kernel.
-  if (a.mode == G_3x3 && a.epi != E_SHUFFLE_BIAS && a.M % 256 == 0 && a.Hi == a.Ho && a.Wi == a.Wo) {
-    const int ck = dtype == MI_BF16 ? 32 : 16;
-    int R, G, bands;
-    if (a.Cin % ck == 0 && hconv_tiling(a.Hi, a.Wi, &R, &G, &bands) && (G == 1 || a.B % G == 0)) {
-      HconvArgs h{};
-      h.in = a.in; h.in_cs = a.in_cs; h.in_co = a.in_co;
-      h.w = a.w; h.Kp = a.Kp; h.Cp = a.Cin;
-      h.N = a.N; h.bias = a.epi == E_PLAIN ? nullptr : a.bias; h.n_real = a.n_real; h.relu = a.epi == E_BIAS_RELU;
-      h.out = a.out; h.out_cs = a.out_cs; h.out_co = a.out_co;
-      h.mask = a.mask; h.mask_cs = a.mask_cs; h.mask_co = a.mask_co;
+  {
+    HconvArgs h{};
+    if (hconv_args_for(a, dtype, &h)) {
       if (a.pool != nullptr) {
-        MI_REQUIRE(a.mask == nullptr && a.Hi % 2 == 0 && a.Wi % 2 == 0 && R % 2 == 0 &&
+        MI_REQUIRE(a.mask == nullptr && a.Hi % 2 == 0 && a.Wi % 2 == 0 && h.R % 2 == 0 &&
                        a.pool_cs % 16 == 0 && a.pool_co % 16 == 0 && aligned16(a.pool),
                    "conv3x3_fwd: the pooled output cannot be fused for this shape");
-        h.pool = a.pool; h.pool_cs = a.pool_cs; h.pool_co = a.pool_co;
       }
-      h.W = a.Wi; h.R = R; h.G = G; h.pitch = (a.Wi + 2 + 7) / 8 * 8; h.HR = G * (R + 2) * h.pitch; h.bands = bands;
-      h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
       if (dtype == MI_BF16) {      // the DMA-fed kernel where it applies, else the register-staged one
         const int rc = launch_dconv_bf16(h, s, name);
         if (rc != -1000) return rc;
       }
+      MI_REQUIRE(!two_tensors, "igemm: two-tensor operands are only taken by the DMA-fed 3x3 kernel, which declines this shape");
       return dtype == MI_BF16 ? launch_hconv_bf16(h, s, name) : launch_hconv_f32(h, s, name);
     }
   }
+  MI_REQUIRE(!two_tensors, "igemm: two-tensor operands are only taken by the DMA-fed 3x3 kernel, which declines this shape");
   MI_REQUIRE(a.pool == nullptr, "conv3x3_fwd: the pooled output cannot be fused for this shape");
   // other 3x3 stride-1 convolutions on images of at most 16 pixels take the position-major kernel
   // (skips the taps that fall on the padding, splits K inside the workgroup)
@@ -307,9 +335,13 @@ WgradLayout convt_wgrad_layout(int B, int H, int W, int Cin, int Cout, int dtype
   return l;
 }
 static int hwgrad_args(HwgradArgs& h, const WgradLayout& l, const void* x, int xcs, int xco, const void* dy, int ycs,
-                       int yco, void* ws, int B, int H, int W, int Cin, int split, int Cout) {
+                       int yco, void* ws, int B, int H, int W, int Cin, int split, int Cout, const void* x2 = nullptr,
+                       int x2_c0 = 0) {
   h.dy = dy; h.dy_cs = ycs; h.dy_co = yco; h.Na = pad_ch(Cout);
   h.x = x; h.x_cs = xcs; h.x_co = xco; h.Cb = concat_cp(Cin, split);
+  h.x2 = x2; h.x2_c0 = x2_c0;
+  MI_REQUIRE(x2 == nullptr || (x2_c0 % 32 == 0 && x2_c0 > 0 && x2_c0 < h.Cb && ((uintptr_t)x2 & 15) == 0),
+             "conv3x3_wgrad: the second input tensor must start at a 32-channel boundary");
   h.W = W; h.R = l.R; h.G = l.G; h.pitch = l.pitch; h.HR = l.HR; h.bands = l.bands;
   h.ntiles = B * H * W / 256; h.tiles_per_split = l.tiles_per_split; h.splits = l.splits;
   h.part = (float*)ws;
@@ -338,9 +370,9 @@ int run_conv3x3_wgrad_pair(const Conv3WgradCall& c0, const Conv3WgradCall& c1, f
   if (c0.ws_bytes < l0.part_bytes + l0.sum_bytes || c1.ws_bytes < l1.part_bytes + l1.sum_bytes)
     return fail(MI_ESIZE, "conv3x3_wgrad_pair: workspace too small");
   HwgradArgs h[2]{};
-  int rc = hwgrad_args(h[0], l0, c0.x, c0.xcs, c0.xco, c0.dy, c0.ycs, c0.yco, c0.ws, B, H, W, c0.Cin, c0.split, c0.Cout);
+  int rc = hwgrad_args(h[0], l0, c0.x, c0.xcs, c0.xco, c0.dy, c0.ycs, c0.yco, c0.ws, B, H, W, c0.Cin, c0.split, c0.Cout, c0.x2, c0.x2_c0);
   if (rc) return rc;
-  rc = hwgrad_args(h[1], l1, c1.x, c1.xcs, c1.xco, c1.dy, c1.ycs, c1.yco, c1.ws, B, H, W, c1.Cin, c1.split, c1.Cout);
+  rc = hwgrad_args(h[1], l1, c1.x, c1.xcs, c1.xco, c1.dy, c1.ycs, c1.yco, c1.ws, B, H, W, c1.Cin, c1.split, c1.Cout, c1.x2, c1.x2_c0);
   if (rc) return rc;
   rc = launch_hwgrad_bf16(h, 2, s, name);
   if (rc) return rc;

@@ -78,6 +78,12 @@ struct IgemmArgs {
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;  // optional: out *= (mask > 0)
   void* pool; int pool_cs, pool_co;        // optional (3x3 forward only): also write the 2x2 max-pool of the output
+  // optional (3x3, DMA-fed bf16 kernel only; anything else refuses them): the operand is TWO tensors of the same
+  // channel stride -- input channels from in2_c0 on are channels 0.. of in2, output channels from out2_n0 on are
+  // channels 0.. of out2.  The two halves of a 32+32-channel concat then each fill whole 64-byte pixels of their
+  // own tensor instead of half of every 128-byte line of a shared one.
+  const void* in2; int in2_c0;
+  void* out2; int out2_n0;
   void* kscratch; size_t kscratch_bytes;   // optional: zero-initialised scratch that lets a layer of few pixels split K across workgroups
                                            // (the kernel leaves its counters at zero; concurrent launches must not share it)
   int epi;
@@ -113,6 +119,7 @@ struct WgradArgs {
 struct HwgradArgs {
   const void* dy; int dy_cs, dy_co; int Na;
   const void* x; int x_cs, x_co; int Cb;
+  const void* x2; int x2_c0;                // optional: channels from x2_c0 on are channels 0.. of x2 (same stride x_cs)
   int W, R, G, pitch, HR, bands;
   int ntiles, tiles_per_split, splits;
   float* part;      // [slabs_per_split*splits][Na][9*Cb]
@@ -125,6 +132,7 @@ int hwgrad_slabs_per_split(int Na);
 // One layer's operands for a paired weight-gradient launch (api.hip: run_conv3x3_wgrad_pair).
 struct Conv3WgradCall {
   const void* x; int xcs, xco;
+  const void* x2; int x2_c0;                // optional second tensor of a two-tensor input (see IgemmArgs::in2)
   const void* dy; int ycs, yco;
   float* dW; float* db;
   void* ws; size_t ws_bytes;

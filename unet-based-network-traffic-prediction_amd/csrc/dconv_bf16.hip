@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
               a.pool_cs, a.pool_co, a.Kp, a.Cp, a.n_real, a.relu, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles, a.nchunks,
               a.d_bands.mul, a.d_bands.shift, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift,
               d.na, d.a_slot, d.w_base, d.w_resident, d.pa, d.remap, d.gx, d.ny, d.d_ny.mul, d.d_ny.shift, d.d_gx.mul, d.d_gx.shift,
-              d.m_grp, d.m_pitch);
+              d.m_grp, d.m_pitch, a.in2, a.chunk2, a.out2, a.n2);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #ifdef MI_DCONV_DIAG
   const long long r_entry = (long long)__builtin_amdgcn_s_memrealtime();
@@ -178,7 +178,9 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
         if (lw + 4 * i < WP) dma16(rs, w_voff[i], dst + i * 4096);
     };
     auto issue_a = [&](int tile, int chunk, int slot) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + ((int64_t)tile * BM * a.in_cs + a.in_co + chunk * CK - margin));
+      // a two-tensor input: the chunks from chunk2 on are the first chunks of the second tensor
+      const T* src = (a.in2 != nullptr && chunk >= a.chunk2) ? (const T*)a.in2 + (chunk - a.chunk2) * CK : in + a.in_co + chunk * CK;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + ((int64_t)tile * BM * a.in_cs - margin));
       char* dst = smem + slot * d.a_slot + lw * 1024;
       if (a.bands == 1) {
 #pragma unroll
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
-  T* __restrict__ out = (T*)a.out;
+  // a two-tensor output: the lanes whose channels lie beyond n2 write the second tensor (a lane's run of
+  // channels never straddles n2: both are multiples of 16)
+  T* __restrict__ out = (a.out2 != nullptr && n0 + 4 * TN * ch >= a.n2) ? (T*)a.out2 - a.n2 - a.out_co : (T*)a.out;
   const T* __restrict__ mask = (const T*)a.mask;
   // ReLU mask of the tile (dgrad): fetched at the START of the tile's last stage, so the loads land
   // behind that stage's MFMAs instead of stalling the epilogue for a round trip to memory
@@ -498,8 +502,8 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 }
 
 // Launches the DMA-fed kernel when the layer suits it; returns -1000 when the caller should use
-// the register-staged kernel instead (an unsuitable shape).
-int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name) {
+// the register-staged kernel instead (an unsuitable shape).  dry_run: decide only, launch nothing.
+int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name, bool dry_run) {
   DconvArgs d{};
   d.h = a_in;
   HconvArgs& a = d.h;
@@ -507,6 +511,7 @@ int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name) {
   a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
   const bool rowpar = a.pitch == 8;                 // 4-wide images: the row-parity swizzle
   if (a.HR > 768 || (a.HR > kHconvMaxHalo && !rowpar)) return -1000;
+  if (a.out2 != nullptr && (a.n2 % 16 != 0 || a.pool != nullptr || a.mask != nullptr)) return -1000;
   // channel tile: 64 where that still gives every CU a workgroup, else 32 (16 for narrow layers)
   int bn = a.N % 64 == 0 ? 64 : (a.N % 32 == 0 ? 32 : 16);
   if (bn == 64 && a.ntiles * (a.N / 64) < 256 && a.ntiles * (a.N / 32) <= 512) bn = 32;
@@ -533,6 +538,7 @@ int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name) {
   d.d_ny = make_fastdiv(d.ny); d.d_gx = make_fastdiv(gx);
   d.m_grp = ((1u << 20) + (a.R + 2) * a.pitch - 1) / ((a.R + 2) * a.pitch);
   d.m_pitch = ((1u << 20) + a.pitch - 1) / a.pitch;
+  if (dry_run) return MI_OK;                        // the caller only asks whether this kernel takes the layer
   dim3 grid(gx * d.ny);
 #define MI_DCONV(TNV, RP, NAME) { if (name) *name = NAME; hipLaunchKernelGGL((dconv_kernel<TNV, RP>), grid, dim3(kDconvThreads), 0, s, d); }
   if (rowpar) {

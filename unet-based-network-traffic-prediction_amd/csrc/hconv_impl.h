@@ -38,6 +38,10 @@ struct HconvArgs {
   int ntiles, nchunks;
   const void* zero;                     // zero page
   FastDiv d_grp, d_pitch, d_rw, d_w, d_bands;   // by (R+2)*pitch, pitch, R*W, W, bands (filled in by the launcher)
+  // two-tensor operands (DMA-fed kernel only): channel chunks from chunk2 on come from in2, output channels
+  // from n2 on go to out2 (both with the first tensor's stride, starting at their own channel 0)
+  const void* in2; int chunk2;
+  void* out2; int n2;
 };
 
 constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 128)

@@ -75,12 +75,14 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
   constexpr int STAGE = DY_BYTES + X_BYTES;
   constexpr int DY_CPR = NB / 8;               // 16-byte chunks per dy row
   // every argument is fetched here, in one batch of scalar loads, not as dependent round trips at first use
-  hw_pin(a.dy, a.x, a.part, a.rowsum, a.dy_cs, a.dy_co, a.Na, a.x_cs, a.x_co, a.Cb, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles,
+  hw_pin(a.x2, a.x2_c0, a.dy, a.x, a.part, a.rowsum, a.dy_cs, a.dy_co, a.Na, a.x_cs, a.x_co, a.Cb, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles,
          a.tiles_per_split, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift, a.d_bands.mul, a.d_bands.shift);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n0 = bx * NB, c0 = by * 32, z = bz;
   const T* __restrict__ pdy = (const T*)a.dy;
-  const T* __restrict__ px = (const T*)a.x;
+  // a two-tensor input: the channel blocks from x2_c0 on are the first blocks of the second tensor
+  const bool second = a.x2 != nullptr && c0 >= a.x2_c0;
+  const T* __restrict__ px = second ? (const T*)a.x2 + (c0 - a.x2_c0) : (const T*)a.x + a.x_co + c0;
   const int grp_rows = (a.R + 2) * a.pitch;
 
   const int t_begin = z * a.tiles_per_split;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pdy + ((int64_t)tile * 256 * a.dy_cs + a.dy_co + n0)), 0, 0x7fffffff, 0x00020000);
     };
     auto x_rsrc = [&](int tile) {
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(px + ((int64_t)tile * 256 * a.x_cs + a.x_co + c0 - (int64_t)a.W * a.x_cs)), 0,
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(px + ((int64_t)tile * 256 * a.x_cs - (int64_t)a.W * a.x_cs)), 0,
                                                0x7fffffff, 0x00020000);
     };
     auto dma = [&](__amdgpu_buffer_rsrc_t r, unsigned voff, char* dst) {

@@ -38,6 +38,7 @@ int run_conv3x3_wgrad(const void*, int, int, const void*, int, int, float*, floa
 int run_convt_wgrad(const void*, int, int, const void*, int, int, float*, float*, float, float, void*, size_t, int, int,
                     int, int, int, int, hipStream_t, const char**, FinJobs*);
 bool conv3x3_wgrad_pairable(int, int, int, int, int, int, int, int, int, int);
+bool conv3x3_takes_dconv(const IgemmArgs&, int);
 int run_conv3x3_wgrad_pair(const Conv3WgradCall&, const Conv3WgradCall&, float, float, int, int, int, int, hipStream_t,
                            const char**, FinJobs*);
 
@@ -75,6 +76,7 @@ struct mi_unet_plan {
   int L;
   std::vector<int> h, w;       // spatial size per level (index L = bottleneck)
   std::vector<bool> direct;    // decoder j writes its transposed conv straight into cat
+  bool split0;                 // level 0: the two halves of the concat are separate tensors ("cat.0" = skip, "up.0")
   bool out_resize;
   std::vector<Layer> layers;
   std::vector<Tensor> tensors;
@@ -124,6 +126,8 @@ namespace {
 struct View {
   void* p;
   int cs, co;
+  void* p2 = nullptr;   // a two-tensor operand: channels from c2 on are channels 0.. of p2 (same stride)
+  int c2 = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -322,6 +326,7 @@ int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, con
   IgemmArgs a = conv3x3_fwd_args(x.p, x.cs, x.co, r.ws + l.wf_off, r.Bv(l), y.p, y.cs, y.co, B, H, W, l.cin, l.split,
                                  l.cout, 1);
   if (pool) { a.pool = pool->p; a.pool_cs = pool->cs; a.pool_co = pool->co; }
+  if (x.p2) { a.in2 = x.p2; a.in2_c0 = x.c2; }
   if (r.P->ksplit_bytes && !r.P->no_ksplit) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
@@ -334,6 +339,7 @@ int do_conv_dgrad(Run& r, const Layer& l, View dy, View dx, const View* mask, in
   const char* k = nullptr;
   IgemmArgs a = conv3x3_dgrad_args(dy.p, dy.cs, dy.co, r.ws + l.wb_off, dx.p, dx.cs, dx.co, mask ? mask->p : nullptr,
                                    mask ? mask->cs : 0, mask ? mask->co : 0, B, H, W, l.cin, l.split, l.cout);
+  if (dx.p2) { a.out2 = dx.p2; a.out2_n0 = dx.c2; }
   if (r.P->ksplit_bytes && !r.P->no_ksplit) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
@@ -346,7 +352,7 @@ int do_conv_wgrad(Run& r, const Layer& l, View x, View dy, float* grads, float a
 }
 static Conv3WgradCall wgrad_call(const Run& r, const Run::WJob& j) {
   const Layer& l = *j.l;
-  return Conv3WgradCall{j.x.p, j.x.cs, j.x.co, j.dy.p, j.dy.cs, j.dy.co, j.grads + l.w_off, j.grads + l.b_off,
+  return Conv3WgradCall{j.x.p, j.x.cs, j.x.co, j.x.p2, j.x.c2, j.dy.p, j.dy.cs, j.dy.co, j.grads + l.w_off, j.grads + l.b_off,
                         r.ws + l.part_off, l.part_bytes, l.cin, l.split, l.cout};
 }
 static int launch_conv_wgrads(Run& r, hipStream_t ws) {
@@ -370,6 +376,7 @@ static int launch_conv_wgrads(Run& r, hipStream_t ws) {
       }
     }
     const Layer& l = *a.l;
+    if (a.x.p2) return fail(MI_ESTATE, "unet_backward: a two-tensor input reached the unpaired weight-gradient path");
     Scope sc(r.P, ws, a.label.c_str(), flops(a), bytes(a));
     const char* k = nullptr;
     int rc = run_conv3x3_wgrad(a.x.p, a.x.cs, a.x.co, a.dy.p, a.dy.cs, a.dy.co, a.grads + l.w_off, a.grads + l.b_off, a.alpha,
@@ -556,11 +563,30 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   const bool train = true;  // gradient tensors are laid out after the forward ones; an inference-only
                             // caller simply passes mi_unet_plan_workspace_bytes(plan) minus nothing: see fwd_bytes
   (void)train;
+  // Level 0 with at most 32 channels: a pixel of the concat buffer would be 128 bytes, 64 per half, and every
+  // kernel that touches ONE half (the transposed conv and its input gradient, max-pool backward, the skip's
+  // conv) would move half-used 128-byte lines.  Where the three kernels that see BOTH halves take two-tensor
+  // operands (the DMA-fed conv kernel, the halo-tile weight gradient), the halves are separate tensors.
+  P->split0 = false;
+  if (d.dtype == MI_BF16 && pad_ch(d.features[0]) == 32 && 2 * P->h[1] == P->h[0] && 2 * P->w[1] == P->w[0]) {
+    const int f = d.features[0];
+    static char dummy[16];
+    IgemmArgs fa = conv3x3_fwd_args(dummy, 32, 0, dummy, (const float*)dummy, dummy, 32, 0, B, P->h[0], P->w[0], 2 * f, f, f, 1);
+    IgemmArgs ga = conv3x3_dgrad_args(dummy, 32, 0, dummy, dummy, 32, 0, nullptr, 0, 0, B, P->h[0], P->w[0], 2 * f, f, f);
+    fa.in2 = dummy; fa.in2_c0 = 32; ga.out2 = dummy; ga.out2_n0 = 32;
+    P->split0 = conv3x3_takes_dconv(fa, d.dtype) && conv3x3_takes_dconv(ga, d.dtype) &&
+                conv3x3_wgrad_pairable(B, P->h[0], P->w[0], f, 0, f, 2 * f, f, f, d.dtype);
+  }
   add_tensor(P, "x", B, d.height, d.width, d.in_channels, 0, cur);
   for (int l = 0; l < L; ++l) {
     const int f = d.features[l];
     add_tensor(P, "a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
-    add_tensor(P, "cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
+    if (l == 0 && P->split0) {
+      add_tensor(P, "cat.0", B, P->h[0], P->w[0], f, 0, cur);
+      add_tensor(P, "up.0", B, P->h[0], P->w[0], f, 0, cur);
+    } else {
+      add_tensor(P, "cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
+    }
     add_tensor(P, "pool." + std::to_string(l), B, P->h[l + 1], P->w[l + 1], f, 0, cur);
   }
   add_tensor(P, "b1", B, P->h[L], P->w[L], 2 * fb, 0, cur);
@@ -591,7 +617,12 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   for (int l = 0; l < L; ++l) {
     const int f = d.features[l];
     add_tensor(P, "g.a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
-    add_tensor(P, "g.cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
+    if (l == 0 && P->split0) {
+      add_tensor(P, "g.cat.0", B, P->h[0], P->w[0], f, 0, cur);
+      add_tensor(P, "g.up.0", B, P->h[0], P->w[0], f, 0, cur);
+    } else {
+      add_tensor(P, "g.cat." + std::to_string(l), B, P->h[l], P->w[l], 2 * f, 0, cur, 2 * pad_ch(f));
+    }
     // total gradient of the skip tensor (concat half + pool path, ReLU-masked), stored densely: the
     // encoder's wgrad/dgrad then read whole rows instead of half of every g.cat row
     add_tensor(P, "g.skip." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
@@ -658,7 +689,9 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     name_view(a + "bottleneck.3", t + "b2", 0, 2 * fb);
     for (int j = 0; j < L; ++j) {
       const int l = L - 1 - j, f = d.features[l]; const std::string s = std::to_string(j), sl = std::to_string(l);
-      if (P->direct[j]) {
+      if (l == 0 && P->split0) {
+        name_view(a + "ups." + std::to_string(2 * j), t + "up.0", 0, f);
+      } else if (P->direct[j]) {
         name_view(a + "ups." + std::to_string(2 * j), t + "cat." + sl, pad_ch(f), f);
       } else {
         name_view(a + "ups." + std::to_string(2 * j), t + "upraw." + s, 0, f);
@@ -817,7 +850,9 @@ int forward_body(Run& r, int flags) {
     const Layer& c2 = P->layers[P->layer_id("ups." + std::to_string(2 * j + 1) + ".2")];
     const int hin = P->h[l + 1], win = P->w[l + 1];
     View cat = r.view("cat." + sl);
-    View dst = P->direct[j] ? View{cat.p, cat.cs, fp} : r.view("upraw." + s);
+    const bool two = l == 0 && P->split0;               // the concat of this level is two tensors
+    if (two) { cat.p2 = r.view("up.0").p; cat.c2 = fp; }
+    View dst = two ? r.view("up.0") : P->direct[j] ? View{cat.p, cat.cs, fp} : r.view("upraw." + s);
     {
       const double fl = 2.0 * B * hin * win * (double)up.cin * up.cout * 4;
       Scope sc(P, r.s, up.prefix.c_str(), fl, (double)B * hin * win * (up.cin + 4.0 * up.cout) * esz(P));
@@ -966,11 +1001,13 @@ int backward_segments(Run& r, const float* dpred_nchw, float* grads, float alpha
       const int H = P->h[l], W = P->w[l], hin = P->h[l + 1], win = P->w[l + 1];
       View u1 = r.view("u1." + s), gu1 = r.view("g.u1." + s), gu2 = r.view("g.u2." + s);
       View cat = r.view("cat." + sl), gcat = r.view("g.cat." + sl);
+      const bool two = l == 0 && P->split0;             // the concat of this level (and its gradient) is two tensors
+      if (two) { cat.p2 = r.view("up.0").p; cat.c2 = fp; gcat.p2 = r.view("g.up.0").p; gcat.c2 = fp; }
       RUN(do_conv_wgrad(r, c2, u1, gu2, grads, alpha, beta, B, H, W, (c2.prefix + ".wgrad").c_str()));
       RUN(do_conv_dgrad(r, c2, gu2, gu1, &u1, B, H, W, (c2.prefix + ".dgrad").c_str()));
       RUN(do_conv_wgrad(r, c1, cat, gu1, grads, alpha, beta, B, H, W, (c1.prefix + ".wgrad").c_str()));
       RUN(do_conv_dgrad(r, c1, gu1, gcat, nullptr, B, H, W, (c1.prefix + ".dgrad").c_str()));
-      View dyT{gcat.p, gcat.cs, fp};
+      View dyT = two ? r.view("g.up.0") : View{gcat.p, gcat.cs, fp};
       if (!P->direct[j]) {
         View gup = r.view("g.upraw." + s);
         const Tensor& tu = P->tensors[P->tensor_id("g.upraw." + s)];
