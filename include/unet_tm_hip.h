@@ -315,6 +315,20 @@ int mi_unet_plan_ksplit_region(const mi_unet_plan* plan, size_t* ws_offset_bytes
  * side stream ordered BEHIND everything it enqueued (reduce the finished range behind the side stream),
  * 0 when it joined the streams (the range is complete in caller_stream's order: reduce there). */
 int mi_unet_plan_prepare(mi_unet_plan* plan, mi_stream caller_stream);
+/* optimizer.step() (train.py:392, torch.optim.Adam of train.py:497) over ALL parameters of the plan's flat
+ * layout, fused with the packing of the MFMA weight images the next forward and backward read: every
+ * parameter is read once, updated (the arithmetic of mi_adam_step, bit for bit), and the 3x3 / transposed
+ * conv weights are written into both images in `ws` from the updated values -- one launch instead of an
+ * Adam pass plus two packing passes over the masters.  The forward calls that follow on this workspace need
+ * no MI_FWD_REPACK until the parameters change by other means.  `ws` must have seen a forward with
+ * MI_FWD_REPACK before (MI_ESTATE otherwise).  mi_unet_plan_adam_pack_supported: 1 when every layer of the
+ * plan can go through the fused kernel (16-byte aligned weight runs: input channels a multiple of 4, no
+ * padding between the halves of a concatenated input; at most 32 layers), else 0: use mi_adam_step and let
+ * the next forward repack. */
+int mi_unet_plan_adam_pack_supported(const mi_unet_plan* plan);
+int mi_unet_adam_pack(mi_unet_plan* plan, float* params_flat, const float* grads_flat, float* exp_avg,
+                      float* exp_avg_sq, void* ws, size_t ws_bytes, float lr, float beta1, float beta2, float eps,
+                      int step, float grad_scale, mi_stream stream);
 int mi_unet_plan_defer_join(mi_unet_plan* plan, int on);
 void* mi_unet_plan_side_stream(mi_unet_plan* plan, mi_stream caller_stream);
 int mi_unet_plan_last_call_deferred(const mi_unet_plan* plan);

@@ -440,6 +440,54 @@ def test_fused_adam_alone_refreshes_packed_weights_and_checkpoints(ua, dtype):
     assert ((alone[0] - stock[0]).abs() / stock[0].abs()).max().item() < tol
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("arch", [(12, 1, (32, 64, 128, 256), 4, 16, 16), (24, 12, (32, 64, 128, 256, 512), 2, 32, 32),
+                                  (12, 1, (32, 64), 3, 8, 24), (4, 2, (48, 96), 2, 16, 16)])
+def test_adam_step_fused_with_weight_packing_is_bit_identical(ua, dtype, arch):
+    """``FusedAdam(..., model=m)`` steps and writes the packed MFMA weight images in ONE launch
+    (mi_unet_adam_pack) where the plan allows it; the run must equal, bit for bit, the one that steps with
+    the plain Adam kernel and lets the next forward repack (``fuse_pack = False``): losses (forward images),
+    gradients of every later step (backward images), parameters, moments, and an evaluation pass at
+    another batch size (a second plan, which must notice that its own images are stale)."""
+    cin, cout, feats, B, H, W = arch
+    batches = [tuple(t.cuda() for t in O.synthetic_batch(B, cin, cout, H, W, seed=s)) for s in range(5)]
+    crit = ua.MSELoss()
+
+    def run(fuse):
+        torch.manual_seed(0)
+        m = ua.UNet(cin, cout, feats, compute_dtype=dtype).cuda()
+        opt = ua.FusedAdam(m.parameters(), lr=1e-3, model=m)
+        opt.fuse_pack = fuse
+        losses, gnorms = [], []
+        for i, (X, Y) in enumerate(batches):
+            if i % 2 == 0:
+                loss = crit(m(X), Y)
+                opt.zero_grad()
+                loss.backward()
+                gnorms.append(torch.stack([p.grad.norm() for p in m.parameters()]))
+                opt.step()
+                losses.append(loss.detach())
+            else:
+                losses.append(m.train_step(X, Y, opt).clone())
+            if i == 2:
+                with torch.no_grad():
+                    mid = m(batches[0][0][:1]).clone()
+        assert m.last_train_plan.adam_pack_ok
+        with torch.no_grad():
+            final = m(batches[0][0]).clone()
+        named = dict(m.named_parameters())
+        mom = [opt.state[named[k]][key].detach().cpu().clone() for k in sorted(named) for key in ("exp_avg", "exp_avg_sq")]
+        return (torch.stack(losses).cpu(), torch.stack(gnorms).cpu(), [p.detach().cpu().clone() for p in m.parameters()],
+                mom, mid.cpu(), final.cpu())
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        assert torch.equal(x, y)
+    assert a[0][0] != a[0][-1]
+
+
 def test_overlapping_forward_passes_keep_their_activations(ua):
     """What stock autograd gives the reference's module: several forward passes may precede one
     backward, an evaluation may sit between a forward and its backward, gradients accumulate

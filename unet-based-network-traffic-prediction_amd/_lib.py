@@ -80,6 +80,8 @@ SIGNATURES = {
     "mi_unet_plan_side_stream": (_p, [_p, _p]),
     "mi_unet_plan_last_call_deferred": (_i, [_p]),
     "mi_unet_plan_prepare": (_i, [_p, _p]),
+    "mi_unet_plan_adam_pack_supported": (_i, [_p]),
+    "mi_unet_adam_pack": (_i, [_p, _p, _p, _p, _p, _p, _sz, _f, _f, _f, _f, _i, _f, _p]),
     "mi_unet_profile_enable": (_i, [_p, _i]),
     "mi_unet_profile_count": (_i, [_p]),
     "mi_unet_profile_read": (_i, [_p, _i, C.c_char_p, _i, C.c_char_p, _i, C.POINTER(C.c_double),

@@ -212,6 +212,25 @@ int launch_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy,
                         int Hin, int Win, int Hout, int Wout, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                 float eps, int step, float grad_scale, hipStream_t s);
+// Adam step and weight packing in one launch: every parameter is read once, updated, and the 3x3 / transposed
+// conv weights are written into their two MFMA images from the updated values (staged in LDS per block of
+// 8 output x 32 input channels), instead of an Adam pass followed by two packing passes over the masters.
+constexpr int kMaxApackJobs = 32;
+struct ApackJob {
+  int kind;                              // 0: 3x3 conv, 1: transposed conv, 2: plain range (no images)
+  int Cout, Cin, Np, Cp, Kp, Kp2;
+  int units_main;                        // packing units of the weight (the tail units follow)
+  int tail_n;                            // elements of the plain Adam range behind the weight (bias; whole tensor for kind 2)
+  int unit_end;                          // running count of units up to and including this job
+  int64_t w_off, tail_off;               // element offsets into the flat buffers
+  void* wf; void* wb;
+};
+struct ApackJobs { int n; ApackJob job[kMaxApackJobs]; };
+bool apack_layer_ok(int convt, int Cout, int Cin, int split, int64_t w_off);
+int apack_jobs_add(ApackJobs& J, int kind, int Cout, int Cin, int split, int64_t w_off, int64_t tail_off, int tail_n,
+                   void* wf, void* wb);
+int launch_apack(const ApackJobs& J, int dtype, float* p, const float* g, float* m, float* v, float lr, float b1,
+                 float b2, float eps, int step, float grad_scale, hipStream_t s);
 
 // Packed-weight geometry helpers (elements)
 inline int concat_cp(int Cin, int split) {  // padded input channels incl. concat layout

@@ -1192,6 +1192,42 @@ void* mi_unet_plan_side_stream(mi_unet_plan* P, mi_stream main) {
   return (void*)P->side;
 }
 int mi_unet_plan_last_call_deferred(const mi_unet_plan* P) { return P && P->last_deferred ? 1 : 0; }
+// Job table of the fused Adam + packing launch; false when some layer cannot go through it.
+static bool apack_jobs(const mi_unet_plan* P, char* ws, ApackJobs& J) {
+  J.n = 0;
+  for (const auto& l : P->layers) {
+    const int tail_n = (l.cout + 3) / 4 * 4;
+    if (l.kind == K_CONV1) {
+      if (!apack_jobs_add(J, 2, l.cout, l.cin, 0, l.w_off, l.w_off, (int)(l.b_off - l.w_off) + tail_n, nullptr, nullptr)) return false;
+      continue;
+    }
+    const int convt = l.kind == K_CONVT;
+    if (!apack_layer_ok(convt, l.cout, l.cin, l.split, l.w_off)) return false;
+    if (!apack_jobs_add(J, convt ? 1 : 0, l.cout, l.cin, l.split, l.w_off, l.b_off, tail_n, ws ? ws + l.wf_off : nullptr,
+                        ws ? ws + l.wb_off : nullptr))
+      return false;
+  }
+  return true;
+}
+int mi_unet_plan_adam_pack_supported(const mi_unet_plan* P) {
+  if (!P) return 0;
+  ApackJobs J;
+  return apack_jobs(P, nullptr, J) ? 1 : 0;
+}
+int mi_unet_adam_pack(mi_unet_plan* P, float* params_flat, const float* grads_flat, float* exp_avg, float* exp_avg_sq,
+                      void* ws, size_t ws_bytes, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                      mi_stream stream) {
+  MI_REQUIRE(P && params_flat && grads_flat && exp_avg && exp_avg_sq && ws, "unet_adam_pack: null pointer");
+  if (ws_bytes < P->ws_bytes) return fail(MI_ESIZE, "unet_adam_pack: workspace too small");
+  MI_REQUIRE(((uintptr_t)ws & 255) == 0, "unet_adam_pack: workspace must be 256-byte aligned");
+  bool known = false;
+  for (const void* k : P->known_ws) known = known || k == ws;
+  if (!known) return fail(MI_ESTATE, "unet_adam_pack: no forward pass with MI_FWD_REPACK has been run on this workspace");
+  ApackJobs J;
+  if (!apack_jobs(P, (char*)ws, J)) return fail(MI_EINVAL, "unet_adam_pack: a layer of this plan cannot go through the fused kernel");
+  return launch_apack(J, P->d.dtype, params_flat, grads_flat, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale,
+                      (hipStream_t)stream);
+}
 int mi_unet_plan_prepare(mi_unet_plan* P, mi_stream caller_stream) {
   MI_REQUIRE(P, "unet_plan_prepare: null plan");
   ensure_side(P, (hipStream_t)caller_stream);

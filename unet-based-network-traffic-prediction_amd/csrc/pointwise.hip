@@ -1231,31 +1231,45 @@ int launch_bilinear_bwd(const void* dout, int64_t osb, int64_t osc, int64_t osy,
 
 // ------------------------------------------------------------------------------------------
 // Adam over a flat range (torch.optim.Adam defaults: no weight decay, no amsgrad).
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, int64_t n, float b1, float b2, float eps, float step_size,
-                            float inv_bc2_sqrt, float gs) {
-  const int64_t n4 = n / 4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    f32x4_t pv = *(f32x4_t*)(p + 4 * i), gv = *(const f32x4_t*)(g + 4 * i), mv = *(f32x4_t*)(m + 4 * i),
-            vv = *(f32x4_t*)(v + 4 * i);
+struct AdamCoef { float b1, b2, eps, step_size, inv_bc2_sqrt, gs; };
+// The fused multiply-adds are spelled out and contraction is off: the plain Adam kernel and the fused
+// Adam + packing kernel must round identically wherever the compiler inlines this.
+__device__ __forceinline__ void adam_update1(float& p, float g, float& m, float& v, const AdamCoef& c) {
+#pragma clang fp contract(off)
+  const float gq = g * c.gs;
+  m = fmaf(gq - m, 1.f - c.b1, m);                          // exp_avg.lerp_(grad, 1 - beta1)
+  const float g2 = (1.f - c.b2) * gq * gq;
+  v = fmaf(v, c.b2, g2);                                    // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+  const float denom = fmaf(sqrtf(v), c.inv_bc2_sqrt, c.eps);
+  p = fmaf(-c.step_size, m / denom, p);
+}
+__device__ __forceinline__ f32x4_t adam_update4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                float* __restrict__ v, const AdamCoef& c) {
+  f32x4_t pv = *(f32x4_t*)p, gv = *(const f32x4_t*)g, mv = *(f32x4_t*)m, vv = *(f32x4_t*)v;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float gq = gv[q] * gs;
-      mv[q] = mv[q] + (gq - mv[q]) * (1.f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
-      vv[q] = vv[q] * b2 + (1.f - b2) * gq * gq;            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-      const float denom = sqrtf(vv[q]) * inv_bc2_sqrt + eps;
-      pv[q] = pv[q] - step_size * (mv[q] / denom);
-    }
-    *(f32x4_t*)(p + 4 * i) = pv; *(f32x4_t*)(m + 4 * i) = mv; *(f32x4_t*)(v + 4 * i) = vv;
+  for (int q = 0; q < 4; ++q) {
+    float pq = pv[q], mq = mv[q], vq = vv[q];
+    adam_update1(pq, gv[q], mq, vq, c);
+    pv[q] = pq; mv[q] = mq; vv[q] = vq;
   }
+  *(f32x4_t*)p = pv; *(f32x4_t*)m = mv; *(f32x4_t*)v = vv;
+  return pv;
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, const AdamCoef c) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    adam_update4(p + 4 * i, g + 4 * i, m + 4 * i, v + 4 * i, c);
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
     const int64_t i = 4 * n4 + threadIdx.x;
-    const float gq = g[i] * gs;
-    const float mq = m[i] + (gq - m[i]) * (1.f - b1);
-    const float vq = v[i] * b2 + (1.f - b2) * gq * gq;
-    m[i] = mq; v[i] = vq;
-    p[i] = p[i] - step_size * (mq / (sqrtf(vq) * inv_bc2_sqrt + eps));
+    float pq = p[i], mq = m[i], vq = v[i];
+    adam_update1(pq, g[i], mq, vq, c);
+    m[i] = mq; v[i] = vq; p[i] = pq;
   }
+}
+static AdamCoef adam_coef(float lr, float b1, float b2, float eps, int step, float grad_scale) {
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  return AdamCoef{b1, b2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale};
 }
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 int step, float grad_scale, hipStream_t s) {
@@ -1263,11 +1277,189 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
   if (n == 0) return MI_OK;
   MI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
              "adam: pointers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-  const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, n, b1, b2, eps, step_size,
-                     inv_bc2_sqrt, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, p, g, m, v, n,
+                     adam_coef(lr, b1, b2, eps, step, grad_scale));
   return check_hip(hipGetLastError(), "adam");
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam + packing in one launch (see ApackJobs in common.h).  A 256-thread workgroup takes one unit:
+//   3x3 conv:  8 output channels x 32 input positions x 9 taps.  The sources are 8 runs of up to 288 floats
+//              of the (Cout,Cin,3,3) parameter: read with 16-byte loads (p, g, m, v), updated, written back, and
+//              the new values parked in LDS; both images are then written from LDS as 16-byte stores of 8
+//              elements: forward rows wf[n][tap*Cp + c] (runs along c), backward rows wb[c][tap'*Np + n] (runs
+//              along n, taps reversed).  Padding rows, positions and row tails are written as zeros by the units
+//              that own them, so the images never need a memset.
+//   transposed conv: 4 input channels x all (co, 2x2) of the (Cin,Cout,2,2) parameter = one contiguous run.
+//   plain range: 1024 consecutive elements (biases, the 1x1 head): Adam only.
+constexpr int kApackRow = 292;                 // floats per staged row: 288 + 4 (16-byte aligned, spreads the banks)
+constexpr int kApackRows = 8;                  // output channels per 3x3 unit (measured 32 / 16 / 8: 56.5 / 50.8 / 48.6 us per step: more, smaller units spread better over the CUs)
+constexpr int kApackLds = 8192;                // staged elements: a 3x3 unit (8 x 292) or 4 input channels of a transposed conv of up to 512 outputs
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) { *(f32x4_t*)p = f32x4_t{v[0], v[1], v[2], v[3]}; }
+template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, const float* v) {
+  *(bf16x4_t*)p = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+template <typename T, bool ADAM>
+__global__ __launch_bounds__(256) void apack_kernel(const ApackJobs J, float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, const AdamCoef c) {
+  // the updated values are staged in the images' own type: half the LDS for bf16 images, twice the workgroups per CU
+  __shared__ __attribute__((aligned(16))) T sh[kApackLds];
+  int j = 0;
+  while (j < J.n - 1 && (int)blockIdx.x >= J.job[j].unit_end) ++j;
+  const ApackJob& q = J.job[j];
+  const int unit = (int)blockIdx.x - (j > 0 ? J.job[j - 1].unit_end : 0);
+  const int t = threadIdx.x;
+  if (unit >= q.units_main) {                 // plain Adam range behind the weight
+    if (!ADAM) return;
+    const int i = (unit - q.units_main) * 1024 + 4 * t;
+    if (i < q.tail_n) {
+      const int64_t o = q.tail_off + i;
+      adam_update4(p + o, g + o, m + o, v + o, c);
+    }
+    return;
+  }
+  T* wf = (T*)q.wf;
+  T* wb = (T*)q.wb;
+  if (q.kind == 0) {
+    const int npb = (q.Cp + 31) / 32;
+    const int nbk = unit / npb, pb = unit - nbk * npb;
+    const int n0 = nbk * kApackRows, c0 = pb * 32;
+    const int ns = min(kApackRows, q.Np - n0), cs = min(32, q.Cp - c0);              // stored rows / positions of this unit
+    const int nr = max(0, min(kApackRows, q.Cout - n0)), cr = max(0, min(32, q.Cin - c0));   // real ones
+    const int vpr = cr * 9 / 4;                                               // 16-byte vectors per source run
+    // three vectors of every array in flight per thread and pass: loads first, then updates and stores
+    for (int base = 0; base < nr * vpr; base += 3 * 256) {
+      int64_t o[3];
+      int so[3];
+      f32x4_t pv[3], gv[3], mv[3], vv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int idx = base + u * 256 + t;
+        const int ic = idx < nr * vpr ? idx : 0;
+        const int r = ic / vpr, k = ic - r * vpr;
+        o[u] = q.w_off + ((int64_t)(n0 + r) * q.Cin + c0) * 9 + 4 * k;
+        so[u] = idx < nr * vpr ? r * kApackRow + 4 * k : -1;
+        pv[u] = *(const f32x4_t*)(p + o[u]);
+        if (ADAM) { gv[u] = *(const f32x4_t*)(g + o[u]); mv[u] = *(const f32x4_t*)(m + o[u]); vv[u] = *(const f32x4_t*)(v + o[u]); }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (so[u] < 0) continue;
+        if (ADAM) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float pq = pv[u][e], mq = mv[u][e], vq = vv[u][e];
+            adam_update1(pq, gv[u][e], mq, vq, c);
+            pv[u][e] = pq; mv[u][e] = mq; vv[u][e] = vq;
+          }
+          *(f32x4_t*)(p + o[u]) = pv[u]; *(f32x4_t*)(m + o[u]) = mv[u]; *(f32x4_t*)(v + o[u]) = vv[u];
+        }
+        const float val[4] = {pv[u][0], pv[u][1], pv[u][2], pv[u][3]};
+        store4<T>(sh + so[u], val);
+      }
+    }
+    __syncthreads();
+    const int pg = cs / 8;                     // 8-position groups per (row, tap)
+    for (int item = t; item < ns * 9 * pg; item += 256) {
+      const int p8 = item % pg, rt = item / pg, tap = rt % 9, r = rt / 9;
+      float val[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] = (r < nr && p8 * 8 + e < cr) ? to_f<T>(sh[r * kApackRow + (p8 * 8 + e) * 9 + tap]) : 0.f;
+      store8<T>(wf + (int64_t)(n0 + r) * q.Kp + tap * q.Cp + c0 + p8 * 8, val);
+    }
+    if (pb == 0) {                             // row tails [9*Cp, Kp)
+      const int tail = q.Kp - 9 * q.Cp;
+      for (int i = t; i < ns * tail; i += 256) wf[(int64_t)(n0 + i / tail) * q.Kp + 9 * q.Cp + i % tail] = from_f<T>(0.f);
+    }
+    const int ng = ns / 8;                     // 8-channel groups per (position, tap)
+    for (int item = t; item < cs * 9 * ng; item += 256) {
+      const int n8 = item % ng, pt = item / ng, tap = pt % 9, pl = pt / 9;
+      float val[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] = (pl < cr && n8 * 8 + e < nr) ? to_f<T>(sh[(n8 * 8 + e) * kApackRow + pl * 9 + (8 - tap)]) : 0.f;
+      store8<T>(wb + (int64_t)(c0 + pl) * q.Kp2 + tap * q.Np + n0 + n8 * 8, val);
+    }
+    if (nbk == 0) {                            // row tails [9*Np, Kp2)
+      const int tail = q.Kp2 - 9 * q.Np;
+      for (int i = t; i < cs * tail; i += 256) wb[(int64_t)(c0 + i / tail) * q.Kp2 + 9 * q.Np + i % tail] = from_f<T>(0.f);
+    }
+    return;
+  }
+  // transposed conv: input channels ci0 .. ci0+3 (units run over the Kp columns of the forward image)
+  const int ci0 = unit * 4;
+  const int rr = max(0, min(4, q.Cin - ci0));
+  const int Cout = q.Cout, Np = q.Np;
+  for (int idx = t; idx < rr * Cout; idx += 256) {       // one 16-byte vector = the 2x2 taps of one (ci, co)
+    const int64_t o = q.w_off + ((int64_t)ci0 * Cout + idx) * 4;
+    const f32x4_t pv = ADAM ? adam_update4(p + o, g + o, m + o, v + o, c) : *(const f32x4_t*)(p + o);
+    const float val[4] = {pv[0], pv[1], pv[2], pv[3]};
+    store4<T>(sh + 4 * idx, val);
+  }
+  __syncthreads();
+  for (int item = t; item < 4 * Np; item += 256) {       // forward image wf[(g*Np + co)][ci]: 4 consecutive ci
+    const int gq = item / Np, co = item - gq * Np;
+    float val[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) val[e] = (co < Cout && e < rr) ? to_f<T>(sh[(e * Cout + co) * 4 + gq]) : 0.f;
+    store4<T>(wf + (int64_t)(gq * Np + co) * q.Kp + ci0, val);
+  }
+  const int ng = Np / 8;
+  for (int item = t; item < 4 * 4 * ng; item += 256) {   // backward image wb[ci][g*Np + co]: runs along co
+    const int n8 = item % ng, pgq = item / ng, gq = pgq & 3, pl = pgq >> 2;
+    if (ci0 + pl >= q.Cp) continue;
+    float val[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) val[e] = (pl < rr && n8 * 8 + e < Cout) ? to_f<T>(sh[(pl * Cout + n8 * 8 + e) * 4 + gq]) : 0.f;
+    store8<T>(wb + (int64_t)(ci0 + pl) * q.Kp2 + gq * Np + n8 * 8, val);
+  }
+  const int tail = q.Kp2 - 4 * Np;
+  for (int i = t; i < 4 * tail; i += 256) {
+    const int pl = i / tail;
+    if (ci0 + pl < q.Cp) wb[(int64_t)(ci0 + pl) * q.Kp2 + 4 * Np + i % tail] = from_f<T>(0.f);
+  }
+}
+// Whether a layer's weight can go through the fused kernel: 16-byte aligned source runs (input channels a
+// multiple of 4, no padding between the two halves of a concatenated input), the staged block fits in LDS.
+bool apack_layer_ok(int convt, int Cout, int Cin, int split, int64_t w_off) {
+  if (w_off % 4 != 0 || Cin % 4 != 0) return false;
+  if (convt) return 4 * 4 * (int64_t)Cout <= kApackLds && pad_ch(Cout) % 16 == 0;
+  return split == 0 || pad_ch(split) == split;
+}
+int apack_jobs_add(ApackJobs& J, int kind, int Cout, int Cin, int split, int64_t w_off, int64_t tail_off, int tail_n,
+                   void* wf, void* wb) {
+  if (J.n >= kMaxApackJobs) return 0;
+  ApackJob& q = J.job[J.n];
+  q.kind = kind; q.Cout = Cout; q.Cin = Cin; q.w_off = w_off; q.tail_off = tail_off; q.tail_n = tail_n; q.wf = wf; q.wb = wb;
+  q.Np = q.Cp = q.Kp = q.Kp2 = 0; q.units_main = 0;
+  if (kind == 0) {
+    q.Np = pad_ch(Cout); q.Cp = concat_cp(Cin, split); q.Kp = (int)kpad(9 * q.Cp); q.Kp2 = (int)kpad(9 * q.Np);
+    q.units_main = ((q.Np + kApackRows - 1) / kApackRows) * ((q.Cp + 31) / 32);
+  } else if (kind == 1) {
+    q.Np = pad_ch(Cout); q.Cp = pad_ch(Cin); q.Kp = (int)kpad(q.Cp); q.Kp2 = (int)kpad(4 * q.Np);
+    q.units_main = q.Kp / 4;
+  }
+  q.unit_end = (J.n > 0 ? J.job[J.n - 1].unit_end : 0) + q.units_main + (tail_n + 1023) / 1024;
+  ++J.n;
+  return 1;
+}
+int launch_apack(const ApackJobs& J, int dtype, float* p, const float* g, float* m, float* v, float lr, float b1,
+                 float b2, float eps, int step, float grad_scale, hipStream_t s) {
+  MI_REQUIRE(J.n > 0 && p != nullptr, "adam+pack: nothing to do");
+  const bool adam = g != nullptr;
+  MI_REQUIRE(!adam || (m != nullptr && v != nullptr && step >= 1), "adam+pack: moments and a step count >= 1 required");
+  MI_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+             "adam+pack: pointers must be 16-byte aligned");
+  const dim3 grid(J.job[J.n - 1].unit_end);
+  const AdamCoef c = adam ? adam_coef(lr, b1, b2, eps, step, grad_scale) : AdamCoef{};
+  if (dtype == MI_BF16) {
+    if (adam) hipLaunchKernelGGL((apack_kernel<__bf16, true>), grid, dim3(256), 0, s, J, p, g, m, v, c);
+    else hipLaunchKernelGGL((apack_kernel<__bf16, false>), grid, dim3(256), 0, s, J, p, g, m, v, c);
+  } else {
+    if (adam) hipLaunchKernelGGL((apack_kernel<float, true>), grid, dim3(256), 0, s, J, p, g, m, v, c);
+    else hipLaunchKernelGGL((apack_kernel<float, false>), grid, dim3(256), 0, s, J, p, g, m, v, c);
+  }
+  return check_hip(hipGetLastError(), "adam+pack");
 }
 
 // ------------------------------------------------------------------------------------------

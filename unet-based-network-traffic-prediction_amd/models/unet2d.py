@@ -63,6 +63,8 @@ class _Plan:
             self.segments.append((lo.value, hi.value))
         self.packed_version = None   # parameter version the packed weights correspond to
         self.packed_train = False
+        self.ws_ready = False        # a forward pass has packed into this workspace at least once
+        self.adam_pack_ok = bool(L.mi_unet_plan_adam_pack_supported(handle))   # FusedAdam may step and pack in one launch
         # A plan's workspace holds the activations of ONE forward pass.  `generation` counts the
         # passes run on it; `leased` is the generation whose backward is still to come (None = free).
         self.generation = 0
@@ -226,6 +228,7 @@ class UNet(nn.Module):
         self._grad_stage: Optional[torch.Tensor] = None
         self._grad_view_spec = None
         self.last_plan: Optional[_Plan] = None
+        self.last_train_plan: Optional[_Plan] = None      # the plan of the last training-mode forward (FusedAdam packs into it)
         self._step_grad: Optional[torch.Tensor] = None     # train_step(): flat gradients and their views
         self._step_views = None
 
@@ -258,6 +261,7 @@ class UNet(nn.Module):
         self._step_grad = None
         self._step_views = None
         self._plans.clear()
+        self.last_plan = self.last_train_plan = None
         self.__dict__.pop("_param_list", None)
         try:
             return super()._apply(fn, *a, **kw)
@@ -355,8 +359,11 @@ class UNet(nn.Module):
                   "unet_forward")
         if flags & MI_FWD_REPACK:
             plan.packed_version, plan.packed_train = version, train
+            plan.ws_ready = True
         self._last_pred = pred
         self.last_plan = plan
+        if train:
+            self.last_train_plan = plan
         return plan
 
     def _backward_impl(self, plan: _Plan, dpred: torch.Tensor, out: Optional[torch.Tensor], beta: float,

@@ -1,11 +1,16 @@
 """``FusedAdam``: ``torch.optim.Adam`` semantics (train.py:497: default betas/eps, no weight
-decay, no amsgrad) as one HIP kernel launch over the model's flat parameter buffer.
+decay, no amsgrad) as one HIP kernel launch over the model's flat parameter buffer.  Given the
+model (``model=``), the same launch also writes the packed MFMA weight images the next forward and
+backward read, from the updated values (``mi_unet_adam_pack``): the parameters are read once per
+step instead of three times.
 
 State lives where ``torch.optim.Adam`` keeps it -- ``self.state[p]`` with the keys ``step``,
 ``exp_avg`` and ``exp_avg_sq`` -- so ``state_dict()`` / ``load_state_dict()`` round-trip and
 interchange with the stock optimizer.  On the flat path the two moment tensors of every
 parameter are views of one flat buffer each."""
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -14,14 +19,17 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, model=None):
-        """``model`` is accepted for compatibility and not needed: every step bumps the version
-        counter of the parameters it wrote, which is what the U-Net module watches to refresh its
-        packed weights."""
+        """``model`` is optional: every step bumps the version counter of the parameters it wrote,
+        which is what the U-Net module watches to refresh its packed weights.  With the model, a
+        step over its whole flat buffer also packs the weights into the workspace of the model's
+        last training forward (bit-identical parameters and images; ``fuse_pack = False`` turns
+        that off)."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = grad_scale
         self._model = model
+        self.fuse_pack = os.environ.get("UNET_TM_FUSE_PACK", "1")[:1] != "0"     # A/B switch for measurements
         self._flat_state = {}      # per group: step count, flat moment buffers, cached layout
 
     @staticmethod
@@ -52,6 +60,28 @@ class FusedAdam(torch.optim.Optimizer):
         torch._C._increment_version(params)
         if self._model is not None:
             self._model.mark_parameters_changed()
+
+    def _flat_adam(self, params, flat_p, flat_g, m, v, group, step) -> None:
+        """One launch over the flat range; fused with the weight packing when the range is the
+        model's whole flat buffer and its last training plan can take it."""
+        b1, b2 = group["betas"]
+        model = self._model
+        plan = getattr(model, "last_train_plan", None) if (model is not None and self.fuse_pack) else None
+        if (plan is not None and plan.adam_pack_ok and plan.ws_ready and plan.leased is None
+                and model._flat is not None and model._flat.data_ptr() == flat_p.data_ptr()
+                and model._flat.numel() == flat_p.numel() and plan.ws.device == flat_p.device):
+            from ._lib import check, lib
+            from .models.unet2d import _on_device
+            with _on_device(flat_p.device):
+                check(lib().mi_unet_adam_pack(plan.handle, flat_p.data_ptr(), flat_g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                              plan.ws.data_ptr(), plan.ws_bytes, group["lr"], b1, b2, group["eps"], step,
+                                              self.grad_scale, torch.cuda.current_stream(flat_p.device).cuda_stream),
+                      "unet_adam_pack")
+            self._written(params)          # versions move, every plan's images are marked stale ...
+            plan.packed_version, plan.packed_train = model._param_version(), True      # ... except the one just written
+            return
+        ops.adam_step(flat_p, flat_g, m, v, group["lr"], b1, b2, group["eps"], step, self.grad_scale)
+        self._written(params)
 
     def _group_step(self, gi, group) -> dict:
         """The group's running record; the step count is taken from ``self.state`` the first time
@@ -99,10 +129,7 @@ class FusedAdam(torch.optim.Optimizer):
         if go + n > flat_g.numel():
             return False
         st["step"] += 1
-        b1, b2 = group["betas"]
-        ops.adam_step(flat_p, flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2, group["eps"], st["step"],
-                      self.grad_scale)
-        self._written(params)
+        self._flat_adam(params, flat_p, flat_g[go:go + n], st["m"], st["v"], group, st["step"])
         return True
 
     def _adopt_flat_moments(self, st, params, pspan, n, device) -> None:
@@ -151,8 +178,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if "m" not in st or st["m"].numel() != n or st.get("m_base") != pspan[0]:
                     self._adopt_flat_moments(st, params, pspan, n, flat_p.device)
                     st["m_base"] = pspan[0]
-                ops.adam_step(flat_p[po:po + n], flat_g[go:go + n], st["m"], st["v"], group["lr"], b1, b2,
-                              group["eps"], st["step"], self.grad_scale)
+                self._flat_adam(params, flat_p[po:po + n], flat_g[go:go + n], st["m"], st["v"], group, st["step"])
                 # remember the layout: later steps only confirm that nothing moved (see _step_cached)
                 st["layout"] = (tuple(id(p) for p in group["params"]), params, pspan[0],
                                 [p.data_ptr() - pspan[0] for p in params], flat_p[po:po + n])
@@ -169,7 +195,7 @@ class FusedAdam(torch.optim.Optimizer):
                         raise RuntimeError("FusedAdam needs contiguous parameters")
                     ops.adam_step(p, g, ps["exp_avg"], ps["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"],
                                   self.grad_scale)
-            self._written(params)
+                self._written(params)
         return loss
 
     # ------------------------------------------------------------------ checkpoints
