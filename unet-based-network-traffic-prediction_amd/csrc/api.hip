@@ -98,6 +98,8 @@ static bool hconv_args_for(const IgemmArgs& a, int dtype, HconvArgs* out) {
   h.W = a.Wi; h.R = R; h.G = G; h.pitch = (a.Wi + 2 + 7) / 8 * 8; h.HR = G * (R + 2) * h.pitch; h.bands = bands;
   h.ntiles = a.M / 256; h.nchunks = a.Cin / ck; h.zero = a.zero;
   h.in2 = a.in2; h.chunk2 = a.in2_c0 / ck; h.out2 = a.out2; h.n2 = a.out2_n0;
+  h.head_w = a.head_w; h.head_b = a.head_b; h.head_out = a.head_out; h.head_cout = a.head_cout;
+  h.head_hw = a.Hi * a.Wi; h.d_hw = make_fastdiv(a.Hi * a.Wi);
   *out = h;
   return true;
 }
@@ -132,7 +134,10 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
              "igemm: input channel range exceeds the view stride");
   MI_REQUIRE(a.out2 == nullptr || (a.out2_n0 > 0 && a.out2_n0 < a.N && a.out_co + a.out2_n0 <= a.out_cs && a.N - a.out2_n0 <= a.out_cs),
              "igemm: output channel range exceeds the view stride");
-  const bool two_tensors = a.in2 != nullptr || a.out2 != nullptr;
+  const bool two_tensors = a.in2 != nullptr || a.out2 != nullptr || a.head_out != nullptr;   // operands only the DMA-fed kernel takes
+  MI_REQUIRE(a.head_out == nullptr || (a.head_w && a.head_b && a.head_cout >= 1 && a.head_cout <= 2 && a.N == 32 && a.mask == nullptr &&
+                                       a.epi == E_BIAS_RELU),
+             "igemm: the fused 1x1 head needs a 32-channel ReLU layer and at most 2 head outputs");
   MI_REQUIRE(!two_tensors || (dtype == MI_BF16 && a.in2_c0 % 32 == 0 && a.out2_n0 % 16 == 0 && aligned16(a.in2) && aligned16(a.out2)),
              "igemm: two-tensor operands need bf16 and 32-channel-aligned halves");
   // 3x3 layers of so few pixels that a pixel-tiled kernel would leave most CUs idle: K-split kernel

@@ -84,6 +84,11 @@ struct IgemmArgs {
   // own tensor instead of half of every 128-byte line of a shared one.
   const void* in2; int in2_c0;
   void* out2; int out2_n0;
+  // optional (3x3 forward, DMA-fed bf16 kernel with one 32-channel tile only; anything else refuses it): the 1x1
+  // head (models/unet2d.py:59, :89) applied to the layer's output in the epilogue -- head_out[b][co][y][x] =
+  // head_b[co] + sum_c out[b][y][x][c] * head_w[co][c], fp32, from the values as stored (rounded to bf16), in the
+  // summation order of the stand-alone head kernel, hence bit-identical to it.  head_cout <= 2.
+  const float* head_w; const float* head_b; float* head_out; int head_cout;
   void* kscratch; size_t kscratch_bytes;   // optional: zero-initialised scratch that lets a layer of few pixels split K across workgroups
                                            // (the kernel leaves its counters at zero; concurrent launches must not share it)
   int epi;

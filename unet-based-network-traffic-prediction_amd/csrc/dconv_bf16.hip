@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
               a.pool_cs, a.pool_co, a.Kp, a.Cp, a.n_real, a.relu, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles, a.nchunks,
               a.d_bands.mul, a.d_bands.shift, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift,
               d.na, d.a_slot, d.w_base, d.w_resident, d.pa, d.remap, d.gx, d.ny, d.d_ny.mul, d.d_ny.shift, d.d_gx.mul, d.d_gx.shift,
-              d.m_grp, d.m_pitch, a.in2, a.chunk2, a.out2, a.n2);
+              d.m_grp, d.m_pitch, a.in2, a.chunk2, a.out2, a.n2, a.head_w, a.head_b, a.head_out, a.head_cout, a.head_hw,
+              a.d_hw.mul, a.d_hw.shift);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #ifdef MI_DCONV_DIAG
   const long long r_entry = (long long)__builtin_amdgcn_s_memrealtime();
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   const int r16 = lane & 15, ch = lane >> 4;
   int paddr[TM][3];
   int out_off[TM], mask_off[TM], pool_off[TM];
+  int pix_in_tile[TM];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int cpr = a.W >= 16 ? a.W >> 4 : 1;
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       const int hr = hrow + tx;
       paddr[j][tx] = hr * 64 + ((ch ^ hswz<ROWPAR>(hr)) << 4);
     }
+    pix_in_tile[j] = pl;
     out_off[j] = pl * a.out_cs + a.out_co + n0 + 4 * TN * ch;
     mask_off[j] = pl * a.mask_cs + a.mask_co + n0 + 4 * TN * ch;
     const int pooled = g * (a.R >> 1) * (a.W >> 1) + (y >> 1) * (a.W >> 1) + (x >> 1);
@@ -319,6 +322,24 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       if (n0 + CPL * ch + k >= nreal) biasv[k] = 0.f;
   }
 
+  // fused 1x1 head (32-channel tile: TN == 2, a lane holds 8 consecutive channels of its pixel): this lane's weights
+  constexpr int HC = 2;                 // head outputs at most
+  float hwv[HC][8];
+  float hbv[HC];
+  if (TN == 2 && a.head_out != nullptr) {
+#pragma unroll
+    for (int co = 0; co < HC; ++co) {
+      const bool live = co < a.head_cout;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = 8 * ch + q;
+        const float wv = a.head_w[(live && c < a.n_real) ? co * a.n_real + c : 0];
+        hwv[co][q] = (live && c < a.n_real) ? wv : 0.f;
+      }
+      const float bv = a.head_b[live ? co : 0];
+      hbv[co] = live ? bv : 0.f;
+    }
+  }
   f32x4_t acc[TN][TM];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -372,6 +393,22 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
           v[4 * i + q] = (a.relu && !(x > 0.f)) ? 0.f : x;
         }
       store_run(otile + out_off[j], v, CPL);
+      if (TN == 2 && a.head_out != nullptr) {
+        // models/unet2d.py:89 on the values just stored: 8 channels per lane in the stand-alone kernel's order, then the
+        // same butterfly over the pixel's four lanes (lane bits 4 and 5 here)
+        const uint32_t p = (uint32_t)tile * BM + (uint32_t)pix_in_tile[j];
+        const uint32_t b = fdiv(p, a.d_hw), rr = p - b * (uint32_t)a.head_hw;
+#pragma unroll
+        for (int co = 0; co < HC; ++co) {
+          if (co >= a.head_cout) break;
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) s = fmaf((float)(T)v[q], hwv[co][q], s);
+          s += __shfl_xor(s, 16, 64);
+          s += __shfl_xor(s, 32, 64);
+          if (ch == 0) a.head_out[((int64_t)b * a.head_cout + co) * a.head_hw + rr] = s + hbv[co];
+        }
+      }
     }
     if (a.pool != nullptr) {
       // MaxPool2d(2,2) of the tile fused here (models/unet2d.py:68): the window partners are other
@@ -512,6 +549,7 @@ int launch_dconv_bf16(const HconvArgs& a_in, hipStream_t s, const char** name, b
   const bool rowpar = a.pitch == 8;                 // 4-wide images: the row-parity swizzle
   if (a.HR > 768 || (a.HR > kHconvMaxHalo && !rowpar)) return -1000;
   if (a.out2 != nullptr && (a.n2 % 16 != 0 || a.pool != nullptr || a.mask != nullptr)) return -1000;
+  if (a.head_out != nullptr && (a.N != 32 || a.mask != nullptr || a.head_cout < 1 || a.head_cout > 2)) return -1000;
   // channel tile: 64 where that still gives every CU a workgroup, else 32 (16 for narrow layers)
   int bn = a.N % 64 == 0 ? 64 : (a.N % 32 == 0 ? 32 : 16);
   if (bn == 64 && a.ntiles * (a.N / 64) < 256 && a.ntiles * (a.N / 32) <= 512) bn = 32;

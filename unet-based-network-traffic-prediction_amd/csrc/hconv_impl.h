@@ -42,6 +42,9 @@ struct HconvArgs {
   // from n2 on go to out2 (both with the first tensor's stride, starting at their own channel 0)
   const void* in2; int chunk2;
   void* out2; int n2;
+  // fused 1x1 head (DMA-fed kernel, 32-channel tile): see IgemmArgs::head_out
+  const float* head_w; const float* head_b; float* head_out; int head_cout, head_hw;
+  FastDiv d_hw;                         // by the pixels of one image
 };
 
 constexpr int kHconvMaxHalo = 640;      // halo slots of the standard LDS buffer (covers 8 <= W <= 128)

@@ -77,6 +77,7 @@ struct mi_unet_plan {
   std::vector<int> h, w;       // spatial size per level (index L = bottleneck)
   std::vector<bool> direct;    // decoder j writes its transposed conv straight into cat
   bool split0;                 // level 0: the two halves of the concat are separate tensors ("cat.0" = skip, "up.0")
+  bool fuse_head;              // the 1x1 head rides in the epilogue of the last 3x3 conv (no launch, no re-read of its output)
   bool out_resize;
   std::vector<Layer> layers;
   std::vector<Tensor> tensors;
@@ -151,6 +152,7 @@ struct Run {   // per-call context
   const float* params;
   hipStream_t s;
   int rc;
+  float* head_out = nullptr;   // forward: where the last conv's epilogue writes the head's output (fused head), else null
   // weight-gradient launches of the current backward segment, issued together by flush_wgrads()
   std::vector<std::function<int(hipStream_t)>> deferred;
   struct WJob { const struct Layer* l; View x, dy; float* grads; float alpha, beta; int B, H, W; std::string label; };
@@ -318,7 +320,8 @@ bool defer_to_side(Run& r, int seg_hi) {
     if (rc__ != MI_OK) return rc__; \
   } while (0)
 
-int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, const char* label, const View* pool = nullptr) {
+int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, const char* label, const View* pool = nullptr,
+                const Layer* head = nullptr) {
   const double fl = 2.0 * B * H * W * (double)l.cout * l.cin * 9;
   const double by = (double)B * H * W * (l.cin + l.cout * (pool ? 1.25 : 1.0)) * esz(r.P);
   Scope sc(r.P, r.s, label, fl, by);
@@ -327,6 +330,7 @@ int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, con
                                  l.cout, 1);
   if (pool) { a.pool = pool->p; a.pool_cs = pool->cs; a.pool_co = pool->co; }
   if (x.p2) { a.in2 = x.p2; a.in2_c0 = x.c2; }
+  if (head) { a.head_w = r.W(*head); a.head_b = r.Bv(*head); a.head_out = r.head_out; a.head_cout = head->cout; }
   if (r.P->ksplit_bytes && !r.P->no_ksplit) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
   sc.kernel(k);
@@ -576,6 +580,15 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     fa.in2 = dummy; fa.in2_c0 = 32; ga.out2 = dummy; ga.out2_n0 = 32;
     P->split0 = conv3x3_takes_dconv(fa, d.dtype) && conv3x3_takes_dconv(ga, d.dtype) &&
                 conv3x3_wgrad_pairable(B, P->h[0], P->w[0], f, 0, f, 2 * f, f, f, d.dtype);
+  }
+  // The 1x1 head in the epilogue of the last 3x3 conv, where that conv runs as ONE 32-channel tile of the DMA-fed kernel.
+  P->fuse_head = false;
+  if (d.dtype == MI_BF16 && pad_ch(d.features[0]) == 32 && d.out_channels <= 2) {
+    const int f = d.features[0];
+    static char dummy[16];
+    IgemmArgs fa = conv3x3_fwd_args(dummy, 32, 0, dummy, (const float*)dummy, dummy, 32, 0, B, P->h[0], P->w[0], f, 0, f, 1);
+    fa.head_w = fa.head_b = (const float*)dummy; fa.head_out = (float*)dummy; fa.head_cout = d.out_channels;
+    P->fuse_head = conv3x3_takes_dconv(fa, d.dtype);
   }
   add_tensor(P, "x", B, d.height, d.width, d.in_channels, 0, cur);
   for (int l = 0; l < L; ++l) {
@@ -876,7 +889,8 @@ int forward_body(Run& r, int flags) {
     }
     View u1 = r.view("u1." + s), u2 = r.view("u2." + s);
     RUN(do_conv_fwd(r, c1, cat, u1, B, P->h[l], P->w[l], c1.prefix.c_str()));
-    RUN(do_conv_fwd(r, c2, u1, u2, B, P->h[l], P->w[l], c2.prefix.c_str()));
+    RUN(do_conv_fwd(r, c2, u1, u2, B, P->h[l], P->w[l], c2.prefix.c_str(), nullptr,
+                    (j == L - 1 && r.head_out != nullptr) ? &P->layers.back() : nullptr));
     cur = u2;
   }
   return MI_OK;
@@ -887,6 +901,11 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
   const mi_unet_desc& d = P->d;
   const int L = P->L, B = d.batch, dt = d.dtype;
   Run r{P, (char*)ws, params_flat, stream, 0};
+  // the 1x1 head in the last conv's epilogue: not under captured launch graphs (the prediction is a per-call
+  // buffer and would become part of the replayed body)
+  const bool fuse_head = P->fuse_head && P->graph_mode == 0;
+  float* pred0 = P->out_resize ? (float*)(r.ws + P->tensors[P->tensor_id("pred0")].off) : pred_nchw;
+  if (fuse_head) r.head_out = pred0;
 
   if (phases & PH_IN) {
     Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
@@ -905,8 +924,7 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
   if (phases & PH_OUT) {
     const Layer& hd = P->layers.back();
     View cur = r.view("u2." + std::to_string(L - 1));
-    float* pred0 = P->out_resize ? (float*)(r.ws + P->tensors[P->tensor_id("pred0")].off) : pred_nchw;
-    {
+    if (!fuse_head) {
       Scope sc(P, r.s, "final_conv", 2.0 * B * d.height * d.width * (double)hd.cin * hd.cout,
                (double)B * d.height * d.width * (hd.cin * esz(P) + 4.0 * hd.cout));
       sc.kernel("head_fwd");
