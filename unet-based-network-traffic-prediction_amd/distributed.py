@@ -9,11 +9,14 @@ rank's are scaled by 1/world_size (folded into the weight-gradient kernels' alph
 Bucketing.  Backward runs in segments whose flat gradient ranges are contiguous and
 descend through one flat fp32 buffer (parameters are laid out in forward order), so a
 bucket is a run of consecutive segments = one contiguous slice.  As soon as a bucket's
-kernels are enqueued its all-reduce is started with ``async_op=True``: the process
-group's communication stream waits for the compute stream at that point and the
-collective overlaps with the remaining backward kernels.  Over xGMI (point-to-point
-links) a ring all-reduce is bound by one link, so buckets are few and large (default
-8 MiB) and the tiny early-encoder tail rides in the last bucket.
+kernels are enqueued its collective is issued as a STREAM-ORDERED operation
+(``async_op=False`` on device tensors) on the plan's weight-gradient stream, which has
+caught up with the bucket's kernels: the caller's stream goes on with the next bucket's
+dgrad chain and only later weight gradients queue up behind the exchange; the optimizer
+runs after the last bucket's call has joined the two streams.  (Host tensors -- the gloo
+tests -- keep asynchronous handles, waited for in ``wait_all``.)  Over xGMI
+(point-to-point links) a ring all-reduce is bound by one link, so buckets are few and
+large (default 8 MiB) and the tiny early-encoder tail rides in the last bucket.
 
 Collective per bucket (``mode``): ``"allreduce"`` issues one all-reduce and leaves the
 algorithm to RCCL; ``"rs_ag"`` issues a reduce-scatter followed by an all-gather of the
