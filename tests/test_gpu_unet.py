@@ -142,6 +142,13 @@ def test_rectangular_images_against_oracle(ua, shape, dtype):
     errs = {k: rel(p.grad.cpu(), pgrads[k]) for k, p in model.named_parameters()}
     assert max(errs.values()) < bar["grad"], sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert rel(Xg.grad.cpu(), dX) < bar["grad"]
+    # the level-0 concat: two tensors where the bf16 kernels take two-tensor operands (the upsampled half is then a
+    # tensor of its own: channel offset 0, stride 32), one shared buffer (offset 32 of 64) otherwise
+    up = names["act.ups.%d" % (2 * (len(feats) - 1))]
+    if dtype == "bf16" and shape == (8, 64, 32):
+        assert (up["coff"], up["cstride"]) == (0, 32)
+    if dtype == "fp32":
+        assert (up["coff"], up["cstride"]) == (32, 64)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -486,6 +493,45 @@ def test_adam_step_fused_with_weight_packing_is_bit_identical(ua, dtype, arch):
     for x, y in zip(a[2] + a[3], b[2] + b[3]):
         assert torch.equal(x, y)
     assert a[0][0] != a[0][-1]
+
+
+def test_adam_pack_entry_point_states_and_limits(ua):
+    """mi_unet_adam_pack through the C ABI: refused on a workspace no repacking forward has initialised
+    (MI_ESTATE), refused for a plan whose layers cannot go through the fused kernel (a concatenated input whose
+    halves are padded: mi_unet_plan_adam_pack_supported says so first), and FusedAdam falls back to the plain
+    step there with the same results as without the model."""
+    import ctypes as C
+    L = ua.lib()
+    torch.manual_seed(0)
+    m = ua.UNet(12, 1, (32, 64), compute_dtype="bf16").cuda()
+    X, Y = (t.cuda() for t in O.synthetic_batch(4, 12, 1, 16, 16, seed=1))
+    loss = ua.MSELoss()(m(X), Y)
+    loss.backward()
+    plan = m.last_train_plan
+    assert L.mi_unet_plan_adam_pack_supported(plan.handle) == 1
+    flat = m.flat_parameters()
+    g = torch.zeros_like(flat); mm = torch.zeros_like(flat); vv = torch.zeros_like(flat)
+    other = torch.empty(plan.ws_bytes, device="cuda", dtype=torch.uint8)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = L.mi_unet_adam_pack(plan.handle, flat.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), other.data_ptr(),
+                             plan.ws_bytes, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, stream)
+    assert rc != 0 and b"MI_FWD_REPACK" in L.mi_last_error()
+    rc = L.mi_unet_adam_pack(plan.handle, flat.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), plan.ws.data_ptr(),
+                             plan.ws_bytes - 256, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, stream)
+    assert rc != 0 and b"too small" in L.mi_last_error()
+    torch.cuda.synchronize()
+
+    torch.manual_seed(0)
+    small = ua.UNet(12, 1, (8, 16), compute_dtype="bf16").cuda()          # 8 + 8 channels concatenated: padded halves
+    opt = ua.FusedAdam(small.parameters(), lr=1e-3, model=small)
+    l0 = small.train_step(X, Y, opt)
+    assert L.mi_unet_plan_adam_pack_supported(small.last_train_plan.handle) == 0 and not small.last_train_plan.adam_pack_ok
+    l1 = small.train_step(X, Y, opt)
+    torch.manual_seed(0)
+    ref = ua.UNet(12, 1, (8, 16), compute_dtype="bf16").cuda()
+    ropt = ua.FusedAdam(ref.parameters(), lr=1e-3)
+    r0 = ref.train_step(X, Y, ropt); r1 = ref.train_step(X, Y, ropt)
+    assert torch.equal(l0, r0) and torch.equal(l1, r1) and l0 != l1
 
 
 def test_overlapping_forward_passes_keep_their_activations(ua):
