@@ -23,6 +23,7 @@
 //     younger stages stay in flight across the barrier (raw s_barrier: __syncthreads would
 //     drain them).
 #include "hconv_impl.h"
+#include <type_traits>
 
 namespace mi {
 
@@ -73,6 +74,22 @@ constexpr unsigned kDmaOob = 0x80000000u;
 // Value of lane+N inside the lane's 16-lane row (DPP row_shl:N); lanes whose source falls outside the row keep their own.
 template <int N> __device__ __forceinline__ float row_shl(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, false));
+}
+// max(a, b) as ONE instruction (the median of a, b and +inf): fmaxf first canonicalises each operand that the
+// compiler cannot prove quiet -- an MFMA result, a DPP move -- with a v_max of its own.  NaN operands give the other one.
+// (The +inf passes through an empty asm: a constant one is folded back into the canonicalising form.)
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float inf = __builtin_inff();
+  asm("" : "+s"(inf));
+  return __builtin_amdgcn_fmed3f(a, b, inf);
+}
+// max(v, v of lane+N inside the 16-lane row) in one DPP instruction; lanes whose source falls outside the row keep v.
+// (Inline assembly is opaque to the compiler's hazard pass: the two wait states a DPP read of a freshly written
+// register needs are written out.)
+template <int N> __device__ __forceinline__ float max_row_shl(float v) {
+  float r = v;
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v), "n"(N));
+  return r;
 }
 template <typename V> __device__ __forceinline__ void pin_scalar(V v) { asm volatile("" ::"s"(v)); }
 template <typename... A> __device__ __forceinline__ void pin_scalars(A... v) { (pin_scalar(v), ...); }
@@ -377,6 +394,44 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   auto epilogue = [&](int tile) {
     T* otile = out + (int64_t)tile * BM * a.out_cs;
     if (mask != nullptr) {
+      // dgrad through a ReLU (models/unet2d.py:30, :40, :53): the gradient survives where the stored activation is
+      // positive.  Done on PAIRS -- both values rounded by one packed conversion, the pair's keep bits from two
+      // packed 16-bit operations on the activations' bit patterns (0 - m, saturating, is negative exactly for
+      // m > 0; its sign, smeared over the half, is the keep mask) -- 2 VALU operations per value; comparing each
+      // activation as a float and selecting each value came to 4.5.
+      typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        uint32_t o[CPL / 2];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int e = 4 * i + 2 * h;       // the pair's first channel inside this lane's run
+            const s16x8_t mw = __builtin_bit_cast(s16x8_t, mreg[j][e / 8]);
+            const s16x2_t m = {mw[e % 8], mw[e % 8 + 1]};
+            const s16x2_t keep = __builtin_elementwise_sub_sat(s16x2_t{0, 0}, m) >> 15;
+            const bf16x2_t r = {(T)acc[i][j][2 * h], (T)acc[i][j][2 * h + 1]};
+            o[e / 2] = __builtin_bit_cast(uint32_t, r) & __builtin_bit_cast(uint32_t, keep);
+          }
+        T* dst = otile + out_off[j];
+        if (CPL >= 8) {
+#pragma unroll
+          for (int k = 0; k < CPL / 8; ++k) *(u32x4_t*)(dst + 8 * k) = u32x4_t{o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]};
+        } else {
+          typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+          *(u32x2_t*)dst = u32x2_t{o[0], o[1]};
+        }
+      }
+      return;
+    }
+    // Two copies of the store loop behind ONE wave-uniform branch, the ReLU as one operation per value: written as
+    // `a.relu ? fmaxf(x, 0.f) : x` it compiled to three VALU operations per value (fmaxf canonicalises its operand
+    // with a max of its own, and the choice became a per-value select) in an epilogue that is VALU-bound.
+    auto store_tile = [&](auto relu_c) {
+      constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         float v[CPL];
@@ -384,50 +439,37 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float x = acc[i][j][q];
-            v[4 * i + q] = (float)mreg[j][(4 * i + q) / 8][(4 * i + q) % 8] > 0.f ? x : 0.f;
+            v[4 * i + q] = RELU ? max_raw(acc[i][j][q], 0.f) : acc[i][j][q];
           }
         store_run(otile + out_off[j], v, CPL);
-      }
-      return;
-    }
+        if (RELU && TN == 2 && a.head_out != nullptr) {     // (the launcher takes a head only behind a ReLU layer)
+          // models/unet2d.py:89 on the values just stored: 8 channels per lane in the stand-alone kernel's order, then the
+          // same butterfly over the pixel's four lanes (lane bits 4 and 5 here)
+          const uint32_t p = (uint32_t)tile * BM + (uint32_t)pix_in_tile[j];
+          const uint32_t b = fdiv(p, a.d_hw), rr = p - b * (uint32_t)a.head_hw;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      float v[CPL];
+          for (int co = 0; co < HC; ++co) {
+            if (co >= a.head_cout) break;
+            float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float x = acc[i][j][q];
-          v[4 * i + q] = a.relu ? fmaxf(x, 0.f) : x;
-        }
-      store_run(otile + out_off[j], v, CPL);
-      if (TN == 2 && a.head_out != nullptr) {
-        // models/unet2d.py:89 on the values just stored: 8 channels per lane in the stand-alone kernel's order, then the
-        // same butterfly over the pixel's four lanes (lane bits 4 and 5 here)
-        const uint32_t p = (uint32_t)tile * BM + (uint32_t)pix_in_tile[j];
-        const uint32_t b = fdiv(p, a.d_hw), rr = p - b * (uint32_t)a.head_hw;
-#pragma unroll
-        for (int co = 0; co < HC; ++co) {
-          if (co >= a.head_cout) break;
-          float s = 0.f;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) s = fmaf((float)(T)v[q], hwv[co][q], s);
-          s += __shfl_xor(s, 16, 64);
-          s += __shfl_xor(s, 32, 64);
-          if (ch == 0) a.head_out[((int64_t)b * a.head_cout + co) * a.head_hw + rr] = s + hbv[co];
+            for (int q = 0; q < 8; ++q) s = fmaf((float)(T)v[q], hwv[co][q], s);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (ch == 0) a.head_out[((int64_t)b * a.head_cout + co) * a.head_hw + rr] = s + hbv[co];
+          }
         }
       }
-    }
+    };
+    if (a.relu) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
     if (a.pool != nullptr) {
       // MaxPool2d(2,2) of the tile fused here (models/unet2d.py:68): the window partners are other
       // lanes of the same wave (column: lane^1; row: the wave's other fragment when W >= 16, lane^W
       // when a fragment holds two or four rows).  max commutes with the rounding to the storage type.
       T* ptile = (T*)a.pool + (int64_t)tile * (BM / 4) * a.pool_cs;
-      auto val = [&](int i, int j, int q) {
-        const float x = acc[i][j][q];
-        return a.relu ? fmaxf(x, 0.f) : x;
-      };
+      // the ReLU goes on the window's maximum (it is monotone: the same value as the maximum of the ReLUs)
+      auto val = [&](int i, int j, int q) { return acc[i][j][q]; };
+      const float floor_v = a.relu ? 0.f : -__builtin_inff();
       // Only the lane of a window's even row and even column stores, and its partners sit at lane+1
       // and lane+W inside its 16-lane row: two DPP row shifts (VALU) instead of LDS-routed shuffles.
       if (a.W >= 16) {
@@ -436,24 +478,28 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float tt = fmaxf(val(i, 0, q), val(i, 1, q));
-            m[4 * i + q] = fmaxf(tt, row_shl<1>(tt));
+            const float tt = max_raw(val(i, 0, q), val(i, 1, q));
+            m[4 * i + q] = max_raw(max_row_shl<1>(tt), floor_v);
           }
         if (pool_off[0] >= 0) store_run(ptile + pool_off[0], m, CPL);
       } else {
+        // one copy of the loop per image width: a per-value choice of the shift became a branch per value
+        auto pool_rows = [&](auto down) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          float m[CPL];
+          for (int j = 0; j < TM; ++j) {
+            float m[CPL];
 #pragma unroll
-          for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float tt = val(i, j, q);
-              tt = fmaxf(tt, a.W == 8 ? row_shl<8>(tt) : row_shl<4>(tt));
-              m[4 * i + q] = fmaxf(tt, row_shl<1>(tt));
-            }
-          if (pool_off[j] >= 0) store_run(ptile + pool_off[j], m, CPL);
-        }
+              for (int q = 0; q < 4; ++q) {
+                const float tt = down(max_raw(val(i, j, q), floor_v));    // (the max first: the DPP source must be a VALU result)
+                m[4 * i + q] = max_row_shl<1>(tt);
+              }
+            if (pool_off[j] >= 0) store_run(ptile + pool_off[j], m, CPL);
+          }
+        };
+        if (a.W == 8) pool_rows([](float x) { return max_row_shl<8>(x); });
+        else pool_rows([](float x) { return max_row_shl<4>(x); });
       }
     }
   };
