@@ -152,13 +152,12 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     int cnt_a = 0;                    // pixel-tile pieces this wave issues per tile
     const unsigned uW = (unsigned)a.W, uR1 = (unsigned)a.R + 1u, RW = (unsigned)(a.R * a.W);
     const bool single = a.bands == 1;
-    // the first tile's pieces are issued as soon as their offsets exist
-    const int band0 = bx - (int)fdiv((uint32_t)bx, a.d_bands) * a.bands;
-    const bool ztop0 = !single && band0 == 0, zbot0 = !single && band0 == a.bands - 1;
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(in + ((int64_t)bx * BM * a.in_cs + a.in_co - margin));
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {      // branch-free: 24-bit multiplies and selects only
+    for (int i = 0; i < A_IT; ++i) {      // branch-free inside a round: 24-bit multiplies and selects only
       const int q = lw + 4 * i;
+      // rounds beyond the tile's pieces (half of them for a 32-wide image) cost nothing: at kernel entry all
+      // twelve waves of the CU run set-up arithmetic and a round takes ~370 cycles instead of ~150
+      if (q >= d.pa) { a_voff[i] = kDmaOob; skipmask |= 1u << i; continue; }
       const unsigned hr = (unsigned)(q * 16 + l4);
       const unsigned g = __umul24(hr, d.m_grp) >> 20, rem = hr - __umul24(g, (unsigned)grp_rows);
       const unsigned hy = __umul24(rem, d.m_pitch) >> 20, hx = rem - __umul24(hy, (unsigned)a.pitch);
@@ -173,14 +172,14 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       skipmask |= (unsigned)(!any) << i;
       cnt_a += any;
     }
-    // the first tile's pieces, once all offsets exist: issued inside the loop above, every round waited for its
-    // own DMA issue and the twelve rounds of arithmetic ran one after the other (2.7 us by in-kernel stamps)
-    {
-      const unsigned z0 = (ztop0 ? topmask : 0u) | (zbot0 ? botmask : 0u);
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i)
-        if (!((skipmask >> i) & 1)) dma16(rs0, ((z0 >> i) & 1) ? kDmaOob : a_voff[i], smem + (lw + 4 * i) * 1024);
-    }
+#ifdef MI_DCONV_DIAG
+    const long long r_offs = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // (the FIRST tile is fetched by the compute waves, which have nothing else to do at kernel entry: each works out
+    // a few pieces' offsets and issues them at once, a microsecond before this wave's offset table is complete)
+#ifdef MI_DCONV_DIAG
+    const long long r_first = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     // all-padding pieces are zeroed in every ring slot, once: no DMA ever writes these bytes
     for (int i = 0; i < A_IT; ++i)
       if (((skipmask >> i) & 1) && lw + 4 * i < d.pa) {
@@ -188,12 +187,16 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
         for (int k = 0; k < NA; ++k) *(u32x4_t*)(smem + k * d.a_slot + (lw + 4 * i) * 1024 + lane * 16) = u32x4_t{0u, 0u, 0u, 0u};
       }
     // weights of the later stages (the compute waves, idle until the first data lands, issue chunk 0 / the resident chunks)
-    unsigned w_voff[W_IT];            // byte offset of this lane's weight source for channel chunk 0
+    unsigned w_voff[W_IT];            // byte offset of this lane's weight source for channel chunk 0 (streamed weights only)
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int q = lw + 4 * i, row = q * 16 + l4;
-      const int tap = row / BN, n = row - tap * BN;
-      w_voff[i] = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
+    for (int i = 0; i < W_IT; ++i) w_voff[i] = kDmaOob;
+    if (!resident) {
+#pragma unroll
+      for (int i = 0; i < W_IT; ++i) {
+        const int q = lw + 4 * i, row = q * 16 + l4;
+        const int tap = row / BN, n = row - tap * BN;
+        w_voff[i] = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
+      }
     }
     auto issue_w = [&](int chunk, int wslot) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + chunk * CK);
@@ -231,21 +234,22 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #ifdef MI_DCONV_DIAG
     const long long r_setup = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    advance_load();                    // tile 0 and the weights are on their way
+    advance_load();                    // tile 0 and the first weights are the compute waves' to fetch
 #ifdef MI_DCONV_DIAG
     const long long r_a0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    int ahead = 0;
-    while (lstage < NA - 1 && lstage < nstages) { issue_a(ltile, lchunk, lslot); advance_load(); ++ahead; }
+    // Stage 0 needs nothing from this wave: it puts the tile of stage 1 on its way, joins the first barrier, and
+    // fetches the other tiles that may be in flight while the compute waves run stage 0.
+    if (lstage < NA - 1 && lstage < nstages) { issue_a(ltile, lchunk, lslot); advance_load(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the one-time zero stores
+    __builtin_amdgcn_s_barrier();
+    while (lstage < NA - 1 && lstage < nstages) { issue_a(ltile, lchunk, lslot); advance_load(); }
 #ifdef MI_DCONV_DIAG
     const long long r_issued = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    wait_vmcnt(ahead * cnt_a);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the one-time zero stores
 #ifdef MI_DCONV_DIAG
     const long long r_landed = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    __builtin_amdgcn_s_barrier();
     int chunk = 0;
     for (int s = 0; s < nstages; ++s) {
       // weight pieces first, pixel pieces after them: the counted wait below relies on that order
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     }
 #ifdef MI_DCONV_DIAG
     if (blockIdx.x == 17 && lane == 0 && wave == 8)
-      printf("dconv loader 8 (x10 ns): entry->zeroed %lld  setup %lld  issue A0 %lld (cnt %d)  issue W+ahead %lld  landed %lld\n", r_zeroed - r_entry,
+      printf("dconv loader 8 (x10 ns): offsets %lld first-issue %lld | entry->zeroed %lld  setup %lld  issue A0 %lld (cnt %d)  issue W+ahead %lld  landed %lld\n", r_offs - r_entry, r_first - r_offs, r_zeroed - r_entry,
              r_setup - r_zeroed, r_a0 - r_setup, cnt_a, r_issued - r_a0, r_landed - r_issued);
 #endif
     return;
@@ -282,6 +286,73 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
   // ================================================================ compute waves
   // (identical maps to hconv_kernel): fragment addresses of this lane's pixel in each of its 2 tiles, per tx
   const int r16 = lane & 15, ch = lane >> 4;
+  // What stage 0 needs is fetched HERE, by the compute waves, in the order it is needed: the bias values, weight
+  // chunk 0, the first pixel tile (each wave works out the offsets of a few pieces and issues them at once; the
+  // loaders' complete offset tables, which serve every later tile, take 1.4 us to build), then the other resident
+  // weight chunks, which may land during stage 0.
+  constexpr int CPL = 4 * TN;
+  float biasv[CPL];
+  {
+    // through a buffer resource that ends at the layer's last real channel: the loads beyond it return zero (a
+    // dgrad launch, which has no bias, gets an empty resource), so there is no index to clamp and no value to
+    // select -- 16 address computations, compares and selects were a fifth of this prologue's instructions
+    const int nreal = a.bias != nullptr ? a.n_real : 0;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias != nullptr ? a.bias : (const float*)a.zero), 0, nreal * 4, 0x00020000);
+    const int boff = (n0 + CPL * ch) * 4;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) biasv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, boff + 4 * k, 0, 0));
+  }
+  int w_later = 0;          // this wave's weight DMAs that stage 0 does not need
+  {
+    constexpr int W_IT8 = (WP + 7) / 8;
+    const int l4 = lane >> 2, cpos = lane & 3;
+    const T* __restrict__ wp = (const T*)a.w;
+    unsigned wv[W_IT8];        // this lane's source offsets inside a chunk: the same for every chunk
+#pragma unroll
+    for (int i = 0; i < W_IT8; ++i) {
+      const int q = wave + 8 * i, row = q * 16 + l4;
+      const int tap = row / BN, n = row - tap * BN;
+      wv[i] = q < WP ? (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u : kDmaOob;
+    }
+    auto issue_chunk = [&](int c) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + c * CK);
+#pragma unroll
+      for (int i = 0; i < W_IT8; ++i)
+        if (wave + 8 * i < WP) dma16(rs, wv[i], smem + d.w_base + c * W_BYTES + (wave + 8 * i) * 1024);
+    };
+    issue_chunk(0);
+    {
+      // pieces wave, wave+8, ... of the first pixel tile (the loaders' arithmetic, without the bookkeeping)
+      const int margin = a.W * a.in_cs;
+      const unsigned uW = (unsigned)a.W, uR1 = (unsigned)a.R + 1u, RW = (unsigned)(a.R * a.W);
+      const bool single = a.bands == 1;
+      const int band0 = bx - (int)fdiv((uint32_t)bx, a.d_bands) * a.bands;
+      const bool ztop0 = !single && band0 == 0, zbot0 = !single && band0 == a.bands - 1;
+      const __amdgpu_buffer_rsrc_t rs0 = make_rsrc((const T*)a.in + ((int64_t)bx * BM * a.in_cs + a.in_co - margin));
+#pragma unroll
+      for (int i = 0; i < (4 * kDconvAIt + 7) / 8; ++i) {
+        const int q = wave + 8 * i;
+        if (q >= d.pa) break;
+        const unsigned hr = (unsigned)(q * 16 + l4);
+        const unsigned g = __umul24(hr, d.m_grp) >> 20, rem = hr - __umul24(g, (unsigned)grp_rows);
+        const unsigned hy = __umul24(rem, d.m_pitch) >> 20, hx = rem - __umul24(hy, (unsigned)a.pitch);
+        const bool top = hy == 0, bot = hy == uR1;
+        const bool on = (hr < (unsigned)a.HR) & (hx - 1u < uW) & !((top | bot) & single) & !(top & ztop0) & !(bot & zbot0);
+        const int pix = (int)(__umul24(g, RW) + __umul24(hy, uW) + hx) - (int)(uW + 1u);
+        const int rel = __mul24(pix, a.in_cs) + ((cpos ^ hswz<ROWPAR>((int)hr)) * EPC);
+        dma16(rs0, on ? (unsigned)(rel + margin) * 2u : kDmaOob, smem + q * 1024);
+      }
+    }
+    if (resident) {
+#pragma unroll 1
+      for (int c = 1; c < a.nchunks; ++c) issue_chunk(c);
+      int mine = 0;
+#pragma unroll
+      for (int i = 0; i < W_IT8; ++i) mine += (wave + 8 * i < WP);
+      w_later = (a.nchunks - 1) * mine;
+    }
+  }
   int paddr[TM][3];
   int out_off[TM], mask_off[TM], pool_off[TM];
   int pix_in_tile[TM];
@@ -311,40 +382,6 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     wfrag[i] = n * 64 + ((ch ^ wswz<TN>(n)) << 4);
   }
   const int ty_bytes = a.pitch * 64;
-
-  // While the loaders work out the pixel-tile geometry, the compute waves (idle until the first data
-  // lands) put the first weights on their way: chunk 0, or every chunk when the weights stay resident.
-  {
-    constexpr int W_IT8 = (WP + 7) / 8;
-    const int l4 = lane >> 2, cpos = lane & 3;
-    const T* __restrict__ wp = (const T*)a.w;
-    const int nw = resident ? a.nchunks : 1;
-    for (int c = 0; c < nw; ++c) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(wp + c * CK);
-#pragma unroll
-      for (int i = 0; i < W_IT8; ++i) {
-        const int q = wave + 8 * i, row = q * 16 + l4;
-        const int tap = row / BN, n = row - tap * BN;
-        const unsigned voff = (unsigned)((n0 + n) * a.Kp + tap * a.Cp + ((cpos ^ wswz<TN>(row)) * EPC)) * 2u;
-        if (q < WP) dma16(rs, voff, smem + d.w_base + c * W_BYTES + q * 1024);
-      }
-    }
-  }
-  constexpr int CPL = 4 * TN;
-  float biasv[CPL];
-  {
-    // all loads issued back to back (clamped index, value selected afterwards): one round trip, not CPL
-    const float* bsrc = a.bias != nullptr ? a.bias : (const float*)a.zero;
-    const int nreal = a.bias != nullptr ? a.n_real : 0;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int n = n0 + CPL * ch + k;
-      biasv[k] = bsrc[n < nreal ? n : 0];
-    }
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      if (n0 + CPL * ch + k >= nreal) biasv[k] = 0.f;
-  }
 
   // fused 1x1 head (32-channel tile: TN == 2, a lane holds 8 consecutive channels of its pixel): this lane's weights
   constexpr int HC = 2;                 // head outputs at most
@@ -507,8 +544,8 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
 #ifdef MI_DCONV_DIAG
   const long long r_ready = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the first weights (and its bias values)
-  __builtin_amdgcn_s_barrier();     // the loaders' prologue: stage 0 has landed
+  wait_vmcnt(w_later);              // this wave's share of weight chunk 0 and of the first pixel tile (and its bias values)
+  __builtin_amdgcn_s_barrier();     // stage 0 has landed
 #ifdef MI_DCONV_DIAG
   const long long r_start = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -573,6 +610,7 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       zero_acc();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (s == 0 && w_later > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the resident weight chunks stage 0 did not need
 #ifdef MI_DCONV_DIAG
     const long long t2 = (long long)__builtin_amdgcn_s_memtime();
 #endif
