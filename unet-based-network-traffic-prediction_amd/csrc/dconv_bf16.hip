@@ -593,6 +593,9 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
     acc[0][0] = mma_slab(wf[0][0], pf[0][0], acc[0][0]);
 #else
     read_tap(0, 0);
+#ifndef MI_DCONV_NO_SCHED
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);     // tap 0's own reads come first
+#endif
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) read_tap(tap + 1, (tap + 1) & 1);
@@ -600,6 +603,21 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = mma_slab(wf[tap & 1][i], pf[tap & 1][j], acc[i][j]);
+#ifndef MI_DCONV_NO_SCHED
+      // The order is spelled out for the scheduler: one fragment read of the NEXT tap in front of each of this tap's
+      // first MFMAs.  Left alone it folds the two register sets into one and issues every read just before its use
+      // (read, wait, MFMA: six waits per tap that only the SIMD's other wave covers).
+      if (tap + 1 < 9) {
+#pragma unroll
+        for (int k = 0; k < TM + TN; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
+#endif
     }
 #endif
 #ifdef MI_DCONV_DIAG
