@@ -91,6 +91,11 @@ template <int N> __device__ __forceinline__ float max_row_shl(float v) {
   asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v), "n"(N));
   return r;
 }
+__device__ __forceinline__ unsigned bf16x2_pack(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t r = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
 template <typename V> __device__ __forceinline__ void pin_scalar(V v) { asm volatile("" ::"s"(v)); }
 template <typename... A> __device__ __forceinline__ void pin_scalars(A... v) { (pin_scalar(v), ...); }
 
@@ -478,7 +483,12 @@ __global__ __launch_bounds__(kDconvThreads) void dconv_kernel(const DconvArgs d)
           for (int q = 0; q < 4; ++q) {
             v[4 * i + q] = RELU ? max_raw(acc[i][j][q], 0.f) : acc[i][j][q];
           }
+#ifdef MI_DCONV_X_NOSTORE
+#pragma unroll
+        for (int k = 0; k < CPL; k += 2) { const float pk = __builtin_bit_cast(float, bf16x2_pack(v[k], v[k + 1])); asm volatile("" ::"v"(pk)); }
+#else
         store_run(otile + out_off[j], v, CPL);
+#endif
         if (RELU && TN == 2 && a.head_out != nullptr) {     // (the launcher takes a head only behind a ReLU layer)
           // models/unet2d.py:89 on the values just stored: 8 channels per lane in the stand-alone kernel's order, then the
           // same butterfly over the pixel's four lanes (lane bits 4 and 5 here)
