@@ -152,6 +152,38 @@ def test_rectangular_images_against_oracle(ua, shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,feats,B,H,W", [(12, (32, 64), 4, 32, 32), (16, (8, 16), 3, 16, 16), (3, (16,), 2, 8, 8),
+                                             (17, (32, 64), 2, 16, 16), (12, (32, 64, 128, 256), 1, 32, 32)])
+def test_narrow_input_pixels_and_a_poisoned_workspace(ua, cin, feats, B, H, W, dtype):
+    """Inputs of up to 16 channels are stored as 16-channel pixels although the first layer reads 32 per pixel: the
+    rest of its chunk is the NEXT pixel (and, behind the last one, a zeroed tail), which meets zero weights.  Nothing
+    a pass reads may be memory it did not write: a workspace filled with NaN bit patterns before the first pass
+    gives bit-identical predictions and gradients (and finite ones) to a zero-filled one."""
+    state = O.init_state_dict(cin, 1, feats, seed=11)
+    X, Y = O.synthetic_batch(B, cin, 1, H, W, seed=12)
+    results = []
+    for fill in (0x00, 0xFF):
+        model = ua.UNet(cin, 1, feats, compute_dtype=dtype)
+        model.load_state_dict(state)
+        model = model.to("cuda")
+        Xg = X.cuda().requires_grad_(True)
+        model._ensure_flat(Xg.device)
+        plan = model._get_plan(Xg.detach(), True)
+        plan.ws.fill_(fill)
+        pred = model(Xg)
+        ua.MSELoss()(pred, Y.cuda()).backward()
+        info = plan.tensors()["act.x"]
+        assert info["cstride"] == (16 if cin <= 16 else 32), info
+        assert torch.equal(model.workspace_tensor("act.x"), X.cuda().to(model.compute_dtype).float())
+        results.append([pred.detach().clone(), Xg.grad.clone()] + [p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*results):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)
+    taps = O.forward_backward(state, X, Y, None)[1]
+    assert rel(results[1][0].cpu(), taps["out"]) < BAR[dtype]["out"]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("arch", [
     # (in, out, features, B, H, W): depths 1..6, widths that are not multiples of 16, one-image batches,
     # sizes that are odd at some level (both bilinear resizes), many output channels.  (The one-level

@@ -130,7 +130,7 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
   MI_REQUIRE(a.epi == E_PLAIN || a.bias != nullptr, "igemm: bias required by this epilogue");
   MI_REQUIRE(a.epi != E_SHUFFLE_BIAS || (a.shufC % 16 == 0 && a.N == 4 * a.shufC), "igemm: bad shuffle width");
   MI_REQUIRE(a.in2 != nullptr ? (a.in_co + a.in2_c0 <= a.in_cs && a.Cin - a.in2_c0 <= a.in_cs && a.in2_c0 > 0 && a.in2_c0 < a.Cin)
-                              : a.in_co + a.Cin <= a.in_cs,
+                              : (a.in_overlap ? (a.in_co == 0 && a.in_cs >= 16) : a.in_co + a.Cin <= a.in_cs),
              "igemm: input channel range exceeds the view stride");
   MI_REQUIRE(a.out2 == nullptr || (a.out2_n0 > 0 && a.out2_n0 < a.N && a.out_co + a.out2_n0 <= a.out_cs && a.N - a.out2_n0 <= a.out_cs),
              "igemm: output channel range exceeds the view stride");

@@ -84,6 +84,11 @@ struct IgemmArgs {
   // own tensor instead of half of every 128-byte line of a shared one.
   const void* in2; int in2_c0;
   void* out2; int out2_n0;
+  // optional: the input view's pixels OVERLAP -- in_cs is smaller than Cin, so a pixel's channels from in_cs on are
+  // the next pixel's first ones (finite numbers) and must meet zero weights.  A 12-channel network input then costs
+  // 16 channels of memory per pixel, not the 32 its first layer's K is padded to.  The caller guarantees Cin - in_cs
+  // readable, finite elements behind the last pixel.
+  int in_overlap;
   // optional (3x3 forward, DMA-fed bf16 kernel with one 32-channel tile only; anything else refuses it): the 1x1
   // head (models/unet2d.py:59, :89) applied to the layer's output in the epilogue -- head_out[b][co][y][x] =
   // head_b[co] + sum_c out[b][y][x][c] * head_w[co][c], fp32, from the values as stored (rounded to bf16), in the
@@ -176,6 +181,9 @@ int launch_finalize_multi(const FinJobs& J, hipStream_t s);
 // ---------------------------------------------------------------- pointwise (pointwise.hip)
 int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W,
                         int dtype, hipStream_t s);
+// The same into overlapping pixels: `width` (a multiple of 16, >= C, = cs) channels are written per pixel instead of
+// pad_ch(C), and `tail` zero elements behind the last pixel.
+int launch_nchw_to_nhwc_narrow(const float* src, void* dst, int width, int tail, int B, int C, int H, int W, int dtype, hipStream_t s);
 int launch_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W,
                         int dtype, hipStream_t s);
 int launch_pack_conv3x3(const float* w, void* wfwd, void* wbwd, int Cout, int Cin, int split, int dtype,

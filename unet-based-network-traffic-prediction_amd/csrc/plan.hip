@@ -77,6 +77,7 @@ struct mi_unet_plan {
   std::vector<int> h, w;       // spatial size per level (index L = bottleneck)
   std::vector<bool> direct;    // decoder j writes its transposed conv straight into cat
   bool split0;                 // level 0: the two halves of the concat are separate tensors ("cat.0" = skip, "up.0")
+  bool x_narrow;               // the input tensor's pixels are 16 channels wide although the first layer reads 32 (they overlap)
   bool fuse_head;              // the 1x1 head rides in the epilogue of the last 3x3 conv (no launch, no re-read of its output)
   bool out_resize;
   std::vector<Layer> layers;
@@ -129,8 +130,10 @@ struct View {
   int cs, co;
   void* p2 = nullptr;   // a two-tensor operand: channels from c2 on are channels 0.. of p2 (same stride)
   int c2 = 0;
+  bool overlap = false; // the pixels overlap: the stride is smaller than the consumer's padded channel count (the input tensor)
 };
 
+constexpr int kInputTail = 64;   // zero elements behind the last pixel of a narrow input tensor (>= 16 of any dtype)
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int add_tensor(mi_unet_plan* P, const std::string& name, int B, int H, int W, int C, int layout, size_t& cursor,
@@ -330,6 +333,7 @@ int do_conv_fwd(Run& r, const Layer& l, View x, View y, int B, int H, int W, con
                                  l.cout, 1);
   if (pool) { a.pool = pool->p; a.pool_cs = pool->cs; a.pool_co = pool->co; }
   if (x.p2) { a.in2 = x.p2; a.in2_c0 = x.c2; }
+  a.in_overlap = x.overlap;
   if (head) { a.head_w = r.W(*head); a.head_b = r.Bv(*head); a.head_out = r.head_out; a.head_cout = head->cout; }
   if (r.P->ksplit_bytes && !r.P->no_ksplit) { a.kscratch = r.ws + r.P->ksplit_off; a.kscratch_bytes = r.P->ksplit_bytes; }
   int rc = launch_igemm(a, r.P->d.dtype, r.s, &k);
@@ -590,7 +594,13 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
     fa.head_w = fa.head_b = (const float*)dummy; fa.head_out = (float*)dummy; fa.head_cout = d.out_channels;
     P->fuse_head = conv3x3_takes_dconv(fa, d.dtype);
   }
-  add_tensor(P, "x", B, d.height, d.width, d.in_channels, 0, cur);
+  // The input: up to 16 channels are stored as 16-channel pixels, although the first layer's K is padded to 32 -- its
+  // chunk then runs on into the next pixel, whose values meet the zero weights of the padding (IgemmArgs::in_overlap).
+  // A 12-channel input costs half the writes of the layout pass and half the reads of the first layer and of its
+  // weight gradient.  Behind the last pixel lie kInputTail zero elements (written by the layout pass).
+  P->x_narrow = d.in_channels <= 16 && pad_ch(d.in_channels) > 16;
+  add_tensor(P, "x", B, d.height, d.width, d.in_channels, 0, cur, P->x_narrow ? 16 : 0);
+  if (P->x_narrow) cur += 256;
   for (int l = 0; l < L; ++l) {
     const int f = d.features[l];
     add_tensor(P, "a1." + std::to_string(l), B, P->h[l], P->w[l], f, 0, cur);
@@ -830,6 +840,7 @@ int forward_body(Run& r, int flags) {
     }
   }
   View cur = r.view("x");
+  cur.overlap = P->x_narrow;
   for (int l = 0; l < L; ++l) {
     const std::string s = std::to_string(l);
     const int f = d.features[l];
@@ -911,7 +922,8 @@ int forward_phases(mi_unet_plan* P, const float* x_nchw, const float* params_fla
     Scope sc(P, r.s, "input_nhwc", 0, (double)B * d.height * d.width * d.in_channels * (4 + esz(P)));
     sc.kernel("nchw_to_nhwc");
     View x = r.view("x");
-    RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
+    if (P->x_narrow) RUN(launch_nchw_to_nhwc_narrow(x_nchw, x.p, x.cs, kInputTail, B, d.in_channels, d.height, d.width, dt, r.s));
+    else RUN(launch_nchw_to_nhwc(x_nchw, x.p, x.cs, 0, B, d.in_channels, d.height, d.width, dt, r.s));
   }
   if (phases & PH_BODY) {
     // Whatever way the body ends, the second stream (the backward weight images, if they were packed

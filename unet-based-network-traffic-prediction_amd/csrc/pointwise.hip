@@ -44,9 +44,14 @@ __device__ __forceinline__ void nchw_to_nhwc_block(const float* __restrict__ sp,
   for (int q = NG * 4; q < 32; q += 4)
     if (q < nstore) store4f(dp + q, f32x4_t{0.f, 0.f, 0.f, 0.f});
 }
+// `tail` zero elements behind the last pixel (a multiple of 4; the overlapping-pixel layout's readable slack)
+template <typename T> __device__ __forceinline__ void nhwc_zero_tail(T* dst, int64_t npix, int cs, int tail) {
+  if (tail > 0 && blockIdx.x == 0 && (int)threadIdx.x * 4 < tail) store4f(dst + npix * cs + threadIdx.x * 4, f32x4_t{0.f, 0.f, 0.f, 0.f});
+}
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
-                                    uint32_t npix, int C, int Cp, uint32_t HW) {
+                                    uint32_t npix, int C, int Cp, uint32_t HW, int tail) {
+  nhwc_zero_tail(dst, (int64_t)npix, cs, tail);
   const uint32_t blocks = (Cp + 31) / 32;
   const uint32_t total = npix * blocks;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -78,21 +83,28 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int cs, int co, f
     dst[((int64_t)b * C + c) * HW + r] = to_f(src[(int64_t)p * cs + co + c]);
   }
 }
-int launch_nchw_to_nhwc_vec(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype, hipStream_t s);
-int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype,
-                        hipStream_t s) {
+int launch_nchw_to_nhwc_vec(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int Cp, int tail, int dtype, hipStream_t s);
+static int launch_nchw_to_nhwc_w(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int Cp, int tail, int dtype,
+                                 hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
-  const int Cp = pad_ch(C);
   if ((H * W) % 4 == 0 && ((uintptr_t)src & 15) == 0 && npix * (Cp / 4) < (1ll << 31))
-    return launch_nchw_to_nhwc_vec(src, dst, cs, co, B, C, H, W, dtype, s);
+    return launch_nchw_to_nhwc_vec(src, dst, cs, co, B, C, H, W, Cp, tail, dtype, s);
   const int64_t total = npix * ((Cp + 31) / 32);
   MI_REQUIRE(total < (1ll << 31), "nchw_to_nhwc: tensor too large");
   const int grid = grid_for(total, 256, 256 * 16);
   if (dtype == MI_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, (uint32_t)npix, C, Cp, (uint32_t)(H * W));
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, (uint32_t)npix, C, Cp, (uint32_t)(H * W), tail);
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, (uint32_t)npix, C, Cp, (uint32_t)(H * W));
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, (uint32_t)npix, C, Cp, (uint32_t)(H * W), tail);
   return check_hip(hipGetLastError(), "nchw_to_nhwc");
+}
+int launch_nchw_to_nhwc(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype,
+                        hipStream_t s) {
+  return launch_nchw_to_nhwc_w(src, dst, cs, co, B, C, H, W, pad_ch(C), 0, dtype, s);
+}
+int launch_nchw_to_nhwc_narrow(const float* src, void* dst, int width, int tail, int B, int C, int H, int W, int dtype, hipStream_t s) {
+  MI_REQUIRE(width % 16 == 0 && width >= C && tail >= 0 && tail % 4 == 0 && tail <= 1024, "nchw_to_nhwc: bad narrow layout");
+  return launch_nchw_to_nhwc_w(src, dst, width, 0, B, C, H, W, width, tail, dtype, s);
 }
 int launch_nhwc_to_nchw(const void* src, int cs, int co, float* dst, int B, int C, int H, int W, int dtype,
                         hipStream_t s) {
@@ -419,8 +431,9 @@ template <> struct Vec16<__bf16> {
 // as one 16-byte store, the lanes of one pixel covering a contiguous run of its row.  Index math is 32-bit.
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_vec_kernel(const float* __restrict__ src, T* __restrict__ dst, int cs, int co,
-                                                               uint32_t nquads, int C, int Cp, uint32_t HW, FastDiv dG, FastDiv dHW4) {
+                                                               uint32_t nquads, int C, int Cp, uint32_t HW, FastDiv dG, FastDiv dHW4, int tail) {
   constexpr int N = Vec16<T>::N;
+  nhwc_zero_tail(dst, (int64_t)nquads * 4, cs, tail);
   const uint32_t G = (uint32_t)Cp / N;
   const uint32_t total = nquads * G;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -449,15 +462,14 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_vec_kernel(const float* __re
     }
   }
 }
-int launch_nchw_to_nhwc_vec(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int dtype, hipStream_t s) {
-  const int Cp = pad_ch(C);
+int launch_nchw_to_nhwc_vec(const float* src, void* dst, int cs, int co, int B, int C, int H, int W, int Cp, int tail, int dtype, hipStream_t s) {
   const uint32_t HW = (uint32_t)(H * W), nquads = (uint32_t)((int64_t)B * HW / 4);
   const int G = Cp / (dtype == MI_BF16 ? 8 : 4);
   const int grid = grid_for((int64_t)nquads * G, 256, 256 * 32);
   if (dtype == MI_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, nquads, C, Cp, HW, make_fastdiv(G), make_fastdiv(HW / 4));
+    hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<__bf16>, dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, cs, co, nquads, C, Cp, HW, make_fastdiv(G), make_fastdiv(HW / 4), tail);
   else
-    hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, nquads, C, Cp, HW, make_fastdiv(G), make_fastdiv(HW / 4));
+    hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, cs, co, nquads, C, Cp, HW, make_fastdiv(G), make_fastdiv(HW / 4), tail);
   return check_hip(hipGetLastError(), "nchw_to_nhwc");
 }
 template <typename T, typename I>
