@@ -251,7 +251,9 @@ int mi_unet_plan_num_params(const mi_unet_plan* plan);
 int mi_unet_plan_param_info(const mi_unet_plan* plan, int i, char* name, int name_cap,
                             int64_t* flat_offset, int64_t shape[4], int* ndim);
 /* Named intermediate tensors inside the workspace (activations "act.*", gradients
- * "grad.*"), for per-layer parity checks.  layout: 0 = NHWC of plan dtype, 1 = fp32 NCHW. */
+ * "grad.*"), for per-layer parity checks.  layout: 0 = NHWC of plan dtype, 1 = fp32 NCHW.
+ * The channel stride of a view is whatever the plan chose: e.g. "act.x" of a network with up to 16 input
+ * channels has stride 16 (its pixels are stored 16 channels wide), other activations of up to 32 channels 32. */
 int mi_unet_plan_num_tensors(const mi_unet_plan* plan);
 int mi_unet_plan_tensor_info(const mi_unet_plan* plan, int i, char* name, int name_cap,
                              int64_t* ws_offset_bytes, int dims[4] /*B,H,W,C*/, int* cstride,
