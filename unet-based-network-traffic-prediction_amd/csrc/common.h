@@ -136,6 +136,7 @@ struct HwgradArgs {
   float* rowsum;    // [slabs_per_split*splits][Na] or null
   const void* zero; // zero page
   FastDiv d_grp, d_pitch, d_rw, d_w, d_bands;   // by (R+2)*pitch, pitch, R*W, W, bands (filled in by the launcher)
+  unsigned m_grp, m_pitch;                      // ceil(2^20 / ((R+2)*pitch)), ceil(2^20 / pitch): 24-bit division of halo rows (launcher)
 };
 bool hwgrad_tiling(int H, int W, int* R, int* G, int* bands, int* pitch, int* HR);
 int hwgrad_slabs_per_split(int Na);

@@ -76,7 +76,7 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
   constexpr int DY_CPR = NB / 8;               // 16-byte chunks per dy row
   // every argument is fetched here, in one batch of scalar loads, not as dependent round trips at first use
   hw_pin(a.x2, a.x2_c0, a.dy, a.x, a.part, a.rowsum, a.dy_cs, a.dy_co, a.Na, a.x_cs, a.x_co, a.Cb, a.W, a.R, a.pitch, a.HR, a.bands, a.ntiles,
-         a.tiles_per_split, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift, a.d_bands.mul, a.d_bands.shift);
+         a.tiles_per_split, a.m_grp, a.m_pitch, a.d_rw.mul, a.d_rw.shift, a.d_w.mul, a.d_w.shift, a.d_bands.mul, a.d_bands.shift);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int n0 = bx * NB, c0 = by * 32, z = bz;
   const T* __restrict__ pdy = (const T*)a.dy;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
     }
     // x halo: piece q covers halo rows [16q, 16q+16); offsets are bytes from (tile's first pixel - one image row)
     const int l4 = lane >> 2, pos4 = lane & 3;
-    const unsigned m_grp = ((1u << 20) + grp_rows - 1) / grp_rows, m_pitch = ((1u << 20) + a.pitch - 1) / a.pitch;
+    const unsigned m_grp = a.m_grp, m_pitch = a.m_pitch;     // (from the launcher: two integer divisions are ~50 instructions here)
     const unsigned uW = (unsigned)a.W, uR1 = (unsigned)a.R + 1u, RW = (unsigned)(a.R * a.W);
     const bool single = a.bands == 1;
     const int npieces = (a.HR + 15) / 16;
@@ -134,6 +134,9 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
 #pragma unroll
     for (int i = 0; i < X_PW; ++i) {
       const int q = lw + 4 * i;
+      // rounds beyond the halo's pieces cost nothing (a 32-wide image has 30 of 48): at kernel entry all twelve waves
+      // of the CU run set-up arithmetic and this loop is bound by instruction issue
+      if (q >= npieces) { x_voff[i] = OOB; skipmask |= 1u << i; continue; }
       const unsigned hr = (unsigned)(q * 16 + l4);
       const unsigned g = __umul24(hr, m_grp) >> 20, rem = hr - __umul24(g, (unsigned)grp_rows);
       const unsigned hy = __umul24(rem, m_pitch) >> 20, hx = rem - __umul24(hy, (unsigned)a.pitch);
@@ -371,6 +374,8 @@ int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const cha
     MI_REQUIRE((a.Na % 64 == 0 ? 64 : 32) == NB, "hwgrad: layers of one launch must share the channel-block width");
     a.d_grp = make_fastdiv((a.R + 2) * a.pitch); a.d_pitch = make_fastdiv(a.pitch); a.d_rw = make_fastdiv(a.R * a.W);
     a.d_w = make_fastdiv(a.W); a.d_bands = make_fastdiv(a.bands);
+    a.m_grp = ((1u << 20) + (a.R + 2) * a.pitch - 1) / ((a.R + 2) * a.pitch);
+    a.m_pitch = ((1u << 20) + a.pitch - 1) / a.pitch;
     p.layer[i] = a;
   }
   // XCD-aware order when no XCD (32 CUs) would be dealt more than 32 workgroups, else the plain one
