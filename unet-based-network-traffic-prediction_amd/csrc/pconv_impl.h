@@ -19,6 +19,7 @@
 // workgroups of one L2 rather than streamed through all eight.
 #pragma once
 #include "igemm_impl.h"
+#include <type_traits>
 
 namespace mi {
 
@@ -84,8 +85,13 @@ __global__ __launch_bounds__(256 * KG) void pconv_kernel(const PconvArgs a) {
     wbase[i] = (int64_t)(n0 + row) * a.Kp + sub * EPC;
   }
 
-  u32x4_t ra[2], rb[2];
-  auto load_stage = [&](int s) {
+  // two register sets: the loads of the stage after next are in flight while this stage computes (one set, with
+  // the load issued at the top of an iteration and stored to LDS at its end, made every iteration as long as a memory
+  // round trip: ~1 us under load for 8 MFMAs per wave)
+  u32x4_t ra2[2][2], rb2[2][2];
+  auto load_stage = [&](int s, int set) {
+    u32x4_t* ra = ra2[set];
+    u32x4_t* rb = rb2[set];
     const int ti = s / cps, cc = s - ti * cps;
     const int tyi = ti / nx;
     const int dy = dy0 + tyi, dx = dx0 + (ti - tyi * nx);
@@ -97,7 +103,9 @@ __global__ __launch_bounds__(256 * KG) void pconv_kernel(const PconvArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) rb[i] = *(const u32x4_t*)(wp + wbase[i] + woff);
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, int set) {
+    const u32x4_t* ra = ra2[set];
+    const u32x4_t* rb = rb2[set];
     char* A = gs + buf * STAGE;
     char* Bt = A + OP_BYTES;
     const int s = sub >> 2, c = sub & 3;
@@ -138,19 +146,23 @@ __global__ __launch_bounds__(256 * KG) void pconv_kernel(const PconvArgs a) {
   // group g takes stages g, g+KG, ...; every group runs the same number of barriers
   const int niter = (nstages + KG - 1) / KG;
   int s = g;
-  if (s < nstages) {
-    load_stage(s);
-    store_stage(0);
-  }
+  if (s < nstages) load_stage(s, 0);
+  if (s + KG < nstages) load_stage(s + KG, 1);
+  if (s < nstages) store_stage(0, 0);
   __syncthreads();
-  for (int it = 0; it < niter; ++it) {
-    const int sn = s + KG;
-    const bool more = sn < nstages;
-    if (more) load_stage(sn);
-    if (s < nstages) compute(it & 1);
-    if (more) store_stage((it + 1) & 1);
-    s = sn;
+  // iteration `it` computes stage s from LDS buffer it&1, issues the loads of stage s+2*KG into the register set
+  // that buffer was filled from, and parks stage s+KG (register set (it+1)&1, loaded an iteration ago) in the other buffer
+  auto iteration = [&](int it, auto par) {
+    constexpr int P = decltype(par)::value;            // it & 1
+    if (s + 2 * KG < nstages) load_stage(s + 2 * KG, P);
+    if (s < nstages) compute(P);
+    if (s + KG < nstages) store_stage(1 - P, 1 - P);
+    s += KG;
     __syncthreads();
+  };
+  for (int it = 0; it < niter; it += 2) {
+    iteration(it, std::integral_constant<int, 0>{});
+    if (it + 1 < niter) iteration(it + 1, std::integral_constant<int, 1>{});
   }
 
   // combine the KG accumulators (fixed order) through LDS; lane holds channels 4*ch..+3 of row r16
