@@ -219,40 +219,44 @@ __device__ __forceinline__ void hwgrad_body(const HwgradArgs& a, const int bx, c
   const bool do_rows = a.rowsum != nullptr && by == 0 && ct == 0;
   const bf16x8_t ones = ones_frag(T());
 
+#ifndef MI_HWGRAD_LEAD
+#define MI_HWGRAD_LEAD 2
+#endif
+  constexpr int kLead = MI_HWGRAD_LEAD;      // steps of lead of the x fragment reads
   auto compute = [&](int buf) {
     const char* S = smem + buf * STAGE;
     // software pipeline over the flattened (k-step, tap) sequence: the fragments of step i+1
     // are read while the MFMAs of step i issue (two register sets, static indices)
-    bf16x8_t af[2][2], bfr[3];
+    bf16x8_t af[2][2], bfr[kLead + 1];
     auto read_a = [&](int k, int set) {
       af[set][0] = tr_pair(S + a_base[0] + k * 32 * ROWB, S + a_base[0] + k * 32 * ROWB + 8 * ROWB);
       af[set][1] = tr_pair(S + a_base[1] + k * 32 * ROWB, S + a_base[1] + k * 32 * ROWB + 8 * ROWB);
     };
-    auto read_b = [&](int idx) {           // x fragment of flattened step idx into set idx % 3
+    auto read_b = [&](int idx) {           // x fragment of flattened step idx into set idx % (kLead + 1)
       const int k = idx / 9, tp = idx % 9;
       const char* Sy = S + (tp / 3) * ty_bytes + (((tp / 3) & 1) ? flipd : 0) + (RP ? (tp % 3) * 64 : 0);
-      bfr[idx % 3] = tr_pair(Sy + b_addr[k][0][RP ? 0 : tp % 3], Sy + b_addr[k][1][RP ? 0 : tp % 3]);
+      bfr[idx % (kLead + 1)] = tr_pair(Sy + b_addr[k][0][RP ? 0 : tp % 3], Sy + b_addr[k][1][RP ? 0 : tp % 3]);
     };
     // x fragments are read TWO steps ahead of their MFMAs (three register sets), the dy fragments of the next
     // k-step at its last-but-one tap, and the order is spelled out for the scheduler: one step of two MFMAs covers
     // ~64 cycles of the SIMD's pipe, less than an LDS round trip, and left alone the compiler keeps one step of lead
     read_a(0, 0);
-    read_b(0);
-    read_b(1);
+#pragma unroll
+    for (int i = 0; i < kLead; ++i) read_b(i);
 #ifndef MI_HWGRAD_NO_SCHED
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * kLead, 0);
 #endif
     constexpr int STEPS = KSP * 9;
 #pragma unroll
     for (int idx = 0; idx < STEPS; ++idx) {
       const int k = idx / 9, tp = idx % 9;
       int nreads = 0;
-      if (idx + 2 < STEPS) { read_b(idx + 2); nreads += 2; }
+      if (idx + kLead < STEPS) { read_b(idx + kLead); nreads += 2; }
       if (tp == 7 && k + 1 < KSP) { read_a(k + 1, (k + 1) & 1); nreads += 4; }
-      acc[tp][0] = mma_px(af[k & 1][0], bfr[idx % 3], acc[tp][0]);
-      acc[tp][1] = mma_px(af[k & 1][1], bfr[idx % 3], acc[tp][1]);
+      acc[tp][0] = mma_px(af[k & 1][0], bfr[idx % (kLead + 1)], acc[tp][0]);
+      acc[tp][1] = mma_px(af[k & 1][1], bfr[idx % (kLead + 1)], acc[tp][1]);
 #ifndef MI_HWGRAD_NO_SCHED
-      if (idx + 2 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      if (idx + kLead < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       if (tp == 7 && k + 1 < KSP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #endif
