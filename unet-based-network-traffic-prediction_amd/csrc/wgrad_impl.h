@@ -17,6 +17,7 @@
 // Row sums of a (bias gradient of a conv) and column sums of b (bias gradient of a
 // transposed conv) come from extra MFMAs against an all-ones fragment.
 #pragma once
+#include <type_traits>
 #include "igemm_impl.h"
 
 namespace mi {
@@ -211,30 +212,61 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const bool do_cols = a.colsum != nullptr && bx == 0 && wr == 0;
   const auto ones = ones_frag(T());
 
-  auto compute = [&](int buf) {
+  // One copy of the k-step loop per (row sums, column sums) combination, chosen by one wave-uniform branch per stage:
+  // with the two flags tested inside every k-step the loop fell into basic blocks and each step read its four
+  // fragments, waited for them and only then issued its MFMAs.  Now the fragments of step ks+1 are read under the
+  // MFMAs of step ks (two register sets; the order is spelled out for the scheduler).
+  auto compute_t = [&](int buf, auto rows_c, auto cols_c) {
+    constexpr bool ROWS = decltype(rows_c)::value, COLS = decltype(cols_c)::value;
     const char* At = smem + buf * 2 * TILE;
     const char* Bt = At + TILE;
-#pragma unroll 4
+    typedef decltype(read_frag_tr(At, 0, 0, lane, T())) frag_t;
+    frag_t fa[2][2], fb[2][2];
+    auto read_step = [&](int ks, int set) {
+      fa[set][0] = read_frag_tr(At, ks, 2 * wr, lane, T());
+      fa[set][1] = read_frag_tr(At, ks, 2 * wr + 1, lane, T());
+      fb[set][0] = read_frag_tr(Bt, ks, 2 * wc, lane, T());
+      fb[set][1] = read_frag_tr(Bt, ks, 2 * wc + 1, lane, T());
+    };
+    constexpr int RD = sizeof(T) == 2 ? 8 : 4;       // LDS read instructions per step (a transposed bf16 fragment is two)
+    constexpr int NM = 4 + (ROWS ? 2 : 0) + (COLS ? 2 : 0);
+    read_step(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      const auto a0 = read_frag_tr(At, ks, 2 * wr, lane, T());
-      const auto a1 = read_frag_tr(At, ks, 2 * wr + 1, lane, T());
-      const auto b0 = read_frag_tr(Bt, ks, 2 * wc, lane, T());
-      const auto b1 = read_frag_tr(Bt, ks, 2 * wc + 1, lane, T());
+      const int c = ks & 1;
+      if (ks + 1 < KSTEPS) read_step(ks + 1, c ^ 1);
       // the b fragment goes in as the row operand: a lane then holds four CONSECUTIVE k of one n,
       // and the partials leave as 16-byte stores
-      acc[0][0] = mma_px(b0, a0, acc[0][0]);
-      acc[0][1] = mma_px(b1, a0, acc[0][1]);
-      acc[1][0] = mma_px(b0, a1, acc[1][0]);
-      acc[1][1] = mma_px(b1, a1, acc[1][1]);
-      if (do_rows) {
-        accr[0] = mma_px(a0, ones, accr[0]);
-        accr[1] = mma_px(a1, ones, accr[1]);
+      acc[0][0] = mma_px(fb[c][0], fa[c][0], acc[0][0]);
+      acc[0][1] = mma_px(fb[c][1], fa[c][0], acc[0][1]);
+      acc[1][0] = mma_px(fb[c][0], fa[c][1], acc[1][0]);
+      acc[1][1] = mma_px(fb[c][1], fa[c][1], acc[1][1]);
+      if (ROWS) {
+        accr[0] = mma_px(fa[c][0], ones, accr[0]);
+        accr[1] = mma_px(fa[c][1], ones, accr[1]);
       }
-      if (do_cols) {
-        accc[0] = mma_px(ones, b0, accc[0]);
-        accc[1] = mma_px(ones, b1, accc[1]);
+      if (COLS) {
+        accc[0] = mma_px(ones, fb[c][0], accc[0]);
+        accc[1] = mma_px(ones, fb[c][1], accc[1]);
+      }
+      if (ks + 1 < KSTEPS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, RD / 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if (NM > 4) __builtin_amdgcn_sched_group_barrier(0x008, NM - 4, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
       }
     }
+  };
+  auto compute = [&](int buf) {
+    if (do_rows && do_cols) compute_t(buf, std::true_type{}, std::true_type{});
+    else if (do_rows) compute_t(buf, std::true_type{}, std::false_type{});
+    else if (do_cols) compute_t(buf, std::false_type{}, std::true_type{});
+    else compute_t(buf, std::false_type{}, std::false_type{});
   };
 
   const int nst = (pend - pbeg + PB - 1) / PB;
