@@ -191,6 +191,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     }
   };
 
+  // Bias of this lane's 4 channels per channel tile, fetched HERE, before the K loop, through a buffer resource that
+  // ends at the last real channel (loads beyond it return zero; no bias: an empty resource).  Loaded in the epilogue
+  // with a clamped index and a select per value, every load was followed by its own wait: eight round trips at the end
+  // of a launch of ~10 us.
+  f32x4_t biasv[TN];
+  {
+    const bool has_bias = a.epi != E_PLAIN;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_bias ? a.bias : (const float*)a.zero), 0, has_bias ? a.n_real * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + (wn * TN + i) * 16 + 4 * (lane >> 4);
+      const int c0 = a.epi == E_SHUFFLE_BIAS ? n % a.shufC : n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) biasv[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (c0 + q) * 4, 0, 0));
+    }
+  }
+
   const int nk = a.Kp / (CPS * EPC);
   load_stage(0);
   store_stage(0);
@@ -210,20 +228,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   // Epilogue: lane holds channels n..n+3 (n = tile*16 + 4*(lane>>4)) of pixel (lane&15).
   T* __restrict__ out = (T*)a.out;
   const T* __restrict__ mask = (const T*)a.mask;
-  // bias of this lane's 4 channels per channel tile, read once with clamped unconditional loads
-  f32x4_t biasv[TN];
+  // ReLU masks of all this lane's outputs, fetched in one batch (one round trip, not one per tile)
+  f32x4_t maskv[TM][TN];
+  if (mask != nullptr) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = n0 + (wn * TN + i) * 16 + 4 * ch;
-    const int c0 = a.epi == E_SHUFFLE_BIAS ? n % a.shufC : n;
+    for (int j = 0; j < TM; ++j) {
+      const int p = p0 + (wm * TM + j) * 16 + r16;
+      const int pc = p < a.M ? p : a.M - 1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float b = 0.f;
-      if (a.epi != E_PLAIN) {
-        b = a.bias[c0 + q < a.n_real ? c0 + q : 0];
-        if (c0 + q >= a.n_real) b = 0.f;
-      }
-      biasv[i][q] = b;
+      for (int i = 0; i < TN; ++i)
+        maskv[j][i] = load4f(mask + (int64_t)pc * a.mask_cs + a.mask_co + n0 + (wn * TN + i) * 16 + 4 * ch);
     }
   }
 #pragma unroll
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         o = opix * a.out_cs + a.out_co + n;
       }
       if (mask != nullptr) {
-        const f32x4_t mv = load4f(mask + (int64_t)p * a.mask_cs + a.mask_co + n);
+        const f32x4_t mv = maskv[j][i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
       }
