@@ -100,6 +100,33 @@ def test_conv3x3_image_geometries(ua, dtype, shape):
     _check_conv3x3(ua, dtype, shape)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(32, 32), (8, 8), (4, 4), (2, 2)])
+def test_conv3x3_dgrad_relu_mask_edge_values(ua, dtype, hw):
+    """The input gradient through a ReLU (models/unet2d.py:30, :40) survives exactly where the stored activation is
+    > 0: +0, -0 and negative values block it, the smallest subnormal and +inf pass it (the bf16 kernels decide on the
+    activation's bit pattern, two values per operation).  Compared with the unmasked gradient value by value."""
+    ops = ua.ops
+    H, W = hw
+    B, Cin, Cout = 8, 64, 32
+    dev = "cuda"
+    w = rnd(dtype, gen(Cout, Cin, 3, 3, seed=2, shift=0.5, scale=0.2))
+    gy = rnd(dtype, gen(B, Cout, H, W, seed=4, shift=0.5))
+    _, wb = ops.pack_conv3x3(w.to(dev), dtype)
+    dyn = ops.to_nhwc(gy.to(dev), dtype)
+    plain = ops.conv3x3_dgrad(dyn, wb, Cin, Cout)
+    tiny = torch.finfo(dtype).smallest_normal * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -23)   # smallest subnormal
+    values = torch.tensor([0.0, -0.0, tiny, -tiny, 1.5, -1.5, float("inf"), -float("inf"), 3e-39, 65504.0], dtype=torch.float32)
+    idx = torch.randint(0, len(values), (B, H, W, plain.shape[3]), generator=torch.Generator().manual_seed(7))
+    mask = values[idx].to(dtype).to(dev)
+    assert (mask.float() == values[idx].to(dtype).float().to(dev)).all()
+    masked = ops.conv3x3_dgrad(dyn, wb, Cin, Cout, mask=mask)
+    keep = mask.float() > 0
+    assert keep.any() and (~keep).any()
+    assert torch.equal(masked[keep], plain[keep])
+    assert torch.count_nonzero(masked[~keep]).item() == 0
+
+
 def _check_conv3x3(ua, dtype, shape):
     B, Cin, Cout, H, W, split = shape
     ops = ua.ops
