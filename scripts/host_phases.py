@@ -34,3 +34,26 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 print("host us per step:", {k: round(v / steps * 1e6, 1) for k, v in acc.items()}, "sum", round(sum(acc.values()) / steps * 1e6, 1),
       "| wall per step (with a sync every 8 steps)", round(wall / steps * 1e6, 1))
+
+# ---- the library calls alone (host time inside the C entry points)
+import ctypes
+L = unet_amd.lib()
+calls = {}
+def wrap(name):
+    f = getattr(L, name)
+    def g(*a):
+        t0 = time.perf_counter()
+        r = f(*a)
+        d = calls.setdefault(name, [0.0, 0])
+        d[0] += time.perf_counter() - t0
+        d[1] += 1
+        return r
+    setattr(L, name, g)
+for n in ("mi_unet_forward", "mi_unet_backward", "mi_mse_fwd_bwd", "mi_unet_adam_pack", "mi_adam_step"):
+    if hasattr(L, n):
+        wrap(n)
+for i in range(steps):
+    one(False)
+    if i % 8 == 7: torch.cuda.synchronize()
+torch.cuda.synchronize()
+print("host us per step inside library calls:", {k: (round(v[0] / steps * 1e6, 1), v[1] // steps) for k, v in calls.items()})
