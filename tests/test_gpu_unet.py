@@ -135,7 +135,7 @@ def test_rectangular_images_against_oracle(ua, shape, dtype):
             e = rel(model.workspace_tensor("act." + k).cpu(), ref)
             assert e < bar["out"], (k, e)
             checked += 1
-            if k.startswith("pool.") and dtype == "fp32":       # max-pool is exact given its input
+            if k.startswith("pool."):       # max-pool is exact given its input (rounding is monotonic: also where it is fused)
                 got_in = model.workspace_tensor("act.downs." + k[5:] + ".3")
                 assert torch.equal(model.workspace_tensor("act." + k), torch.nn.functional.max_pool2d(got_in, 2)), k
     assert checked >= 3 * len(feats) + 2

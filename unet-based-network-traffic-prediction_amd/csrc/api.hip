@@ -29,6 +29,7 @@ int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_dconv_bf16(const HconvArgs& a, hipStream_t s, const char** name, bool dry_run = false);
 bool sconv_applies(const IgemmArgs& a);
+bool sconv_pools(int H, int W, int M);
 int launch_sconv_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
@@ -106,7 +107,8 @@ static bool hconv_args_for(const IgemmArgs& a, int dtype, HconvArgs* out) {
 // Whether a bf16 3x3 layer (forward or dgrad arguments) runs on the DMA-fed halo-tile kernel: the one kernel
 // that takes two-tensor operands (IgemmArgs::in2 / out2).  Mirrors the dispatch of launch_igemm.
 bool conv3x3_takes_dconv(const IgemmArgs& a, int dtype) {
-  if (dtype != MI_BF16 || sconv_applies(a)) return false;
+  // (a layer with the fused head never takes the few-pixel kernel: launch_igemm sends it here whatever its size)
+  if (dtype != MI_BF16 || (a.head_out == nullptr && sconv_applies(a))) return false;
   HconvArgs h{};
   if (!hconv_args_for(a, dtype, &h)) return false;
   if (a.pool != nullptr && !(a.mask == nullptr && a.Hi % 2 == 0 && a.Wi % 2 == 0 && h.R % 2 == 0)) return false;
@@ -185,8 +187,9 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
 }
 
 bool conv3x3_fwd_fuses_pool(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
-  (void)Cout;
   const int M = B * H * W, ck = dtype == MI_BF16 ? 32 : 16;
+  // few pixels (the test of sconv_applies): the K-split kernel pools 32-pixel tiles of narrow images
+  if (dtype == MI_BF16 && concat_cp(Cin, split) % 32 == 0 && (int64_t)M * pad_ch(Cout) < (64 << 13) && sconv_pools(H, W, M)) return true;
   int R, G, bands;
   if (M % 256 != 0 || concat_cp(Cin, split) % ck != 0 || !hconv_tiling(H, W, &R, &G, &bands) || !(G == 1 || B % G == 0))
     return false;

@@ -24,6 +24,7 @@ struct SconvArgs {
   int N; const float* bias; int n_real; int relu;
   void* out; int out_cs, out_co;
   const void* mask; int mask_cs, mask_co;
+  void* pool; int pool_cs, pool_co;     // optional: also write the 2x2 max-pool of the output (W of 4, 8 or 16; 32-pixel tiles)
   int H, W, M;
   int chunks, units;                    // Cp/32, 9*chunks
   int ups, upw;                         // units per K split (blockIdx.z), units per wave within it
@@ -50,6 +51,30 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
   const int n0 = blockIdx.x * (16 * TN), m0 = blockIdx.y * (16 * PF);
   const int HW = a.H * a.W;
 
+  const unsigned wbase = ((unsigned)(n0 + r16) * (unsigned)a.Kp + (unsigned)ch * 8u) * 2u;
+  const __amdgpu_buffer_rsrc_t rin = sconv_rsrc(a.in), rw = sconv_rsrc(a.w);
+
+  const int z1 = ((int)blockIdx.z + 1) * a.ups < a.units ? ((int)blockIdx.z + 1) * a.ups : a.units;
+  const int u0 = (int)blockIdx.z * a.ups + wave * a.upw;
+  const int u1 = u0 + a.upw < z1 ? u0 + a.upw : z1;
+  int tap = (int)fdiv((unsigned)u0, a.d_chunks), c = u0 - tap * a.chunks;
+
+  // The weights of the first batch are asked for before anything else: their addresses need no pixel geometry,
+  // and they are the loads that come from far away (a layer's weights are read once, its few pixels by every workgroup).
+  bf16x8_t wf[U][TN];
+  int wtap = tap, wc = c;
+  auto load_weights = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        wf[i][t] = ld_frag(rw, u + i < u1 ? wbase + (unsigned)(t * 16 * a.Kp + wtap * a.Cp + wc * 32) * 2u : kOob);
+      if (++wc == a.chunks) { wc = 0; ++wtap; }
+    }
+  };
+  load_weights(u0);
+  __builtin_amdgcn_sched_barrier(0);
+
   // per pixel fragment: byte offset of this lane's pixel and the 9-bit set of in-image taps
   unsigned pbase[PF], vtaps[PF];
 #pragma unroll
@@ -68,28 +93,18 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
     vtaps[j] = vt;
     pbase[j] = (pc * (unsigned)a.in_cs + (unsigned)a.in_co + (unsigned)ch * 8u) * 2u;
   }
-  const unsigned wbase = ((unsigned)(n0 + r16) * (unsigned)a.Kp + (unsigned)ch * 8u) * 2u;
-  const __amdgpu_buffer_rsrc_t rin = sconv_rsrc(a.in), rw = sconv_rsrc(a.w);
-
-  const int z1 = ((int)blockIdx.z + 1) * a.ups < a.units ? ((int)blockIdx.z + 1) * a.ups : a.units;
-  const int u0 = (int)blockIdx.z * a.ups + wave * a.upw;
-  const int u1 = u0 + a.upw < z1 ? u0 + a.upw : z1;
-  int tap = (int)fdiv((unsigned)u0, a.d_chunks), c = u0 - tap * a.chunks;
 
   f32x4_t acc[TN * PF];
 #pragma unroll
   for (int j = 0; j < TN * PF; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   for (int u = u0; u < u1; u += U) {
-    bf16x8_t wf[U][TN], pf[U][PF];
+    bf16x8_t pf[U][PF];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const bool on = u + i < u1;
       const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;              // tap / 3, tap % 3 for tap < 9
       const unsigned shift = (unsigned)(((ty - 1) * a.W + (tx - 1)) * a.in_cs + c * 32) * 2u;
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-        wf[i][t] = ld_frag(rw, on ? wbase + (unsigned)(t * 16 * a.Kp + tap * a.Cp + c * 32) * 2u : kOob);
 #pragma unroll
       for (int j = 0; j < PF; ++j)
         pf[i][j] = ld_frag(rin, (on && ((vtaps[j] >> tap) & 1u)) ? pbase[j] + shift : kOob);
@@ -102,6 +117,10 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
       for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int j = 0; j < PF; ++j) acc[t * PF + j] = mma_slab(wf[i][t], pf[i][j], acc[t * PF + j]);
+    if (u + U < u1) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_weights(u + U);
+    }
   }
 
   // K waves combine in wave order
@@ -171,29 +190,67 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
         biasv[q] = n + q < a.n_real ? b : 0.f;
       }
     }
+    f32x4_t v[PF];
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int p = m0 + j * 16 + r16;
-      if (p >= a.M) continue;
-      f32x4_t v = acc[t * PF + j] + biasv;
+      v[j] = acc[t * PF + j] + biasv;
       if (a.relu) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+        for (int q = 0; q < 4; ++q) v[j][q] = v[j][q] > 0.f ? v[j][q] : 0.f;
       }
+      if (p >= a.M) continue;
       if (mask != nullptr) {
         const f32x4_t mv = load4f(mask + (int64_t)p * a.mask_cs + a.mask_co + n);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = mv[q] > 0.f ? v[q] : 0.f;
+        for (int q = 0; q < 4; ++q) v[j][q] = mv[q] > 0.f ? v[j][q] : 0.f;
       }
-      store4f(out + (int64_t)p * a.out_cs + a.out_co + n, v);
+      store4f(out + (int64_t)p * a.out_cs + a.out_co + n, v[j]);
+    }
+    // 2x2 max-pool of the tile, which holds whole row pairs of images 4, 8 or 16 wide.  The window's other
+    // column is the next lane; its other row the lane 4 or 8 further (four or two image rows per 16-pixel
+    // fragment) or, 16 wide, the same lane of the tile's other fragment.  Rounding is monotonic, so the
+    // maximum of the fp32 values rounds to the maximum of the stored ones.
+    {
+      if (a.pool != nullptr) {
+        __bf16* __restrict__ pool = (__bf16*)a.pool;
+        if (a.W == 16) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[0][q] = fmaxf(v[0][q], v[PF - 1][q]);
+        } else {
+          const int dist = a.W;     // 4 or 8 lanes
+#pragma unroll
+          for (int j = 0; j < PF; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[j][q] = fmaxf(v[j][q], __shfl_xor(v[j][q], dist));
+        }
+#pragma unroll
+        for (int j = 0; j < (PF); ++j) {
+          if (a.W == 16 && j == 1) break;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[j][q] = fmaxf(v[j][q], __shfl_xor(v[j][q], 1));
+          const int p = m0 + j * 16 + r16;
+          const unsigned b = fdiv((unsigned)p, a.d_hw), r = (unsigned)p - b * (unsigned)HW;
+          const int y = (int)fdiv(r, a.d_w), x = (int)r - y * a.W;
+          if (p < a.M && !(x & 1) && !(y & 1)) {
+            const int64_t pp = ((int64_t)b * (a.H / 2) + y / 2) * (a.W / 2) + x / 2;
+            store4f(pool + pp * a.pool_cs + a.pool_co + n, v[j]);
+          }
+        }
+      }
     }
   }
 }
 
+// Image shapes whose 2x2 max-pool the few-pixel kernel writes itself: a 16-pixel fragment must hold whole row
+// pairs (images 4 or 8 wide) or the two fragments of a 32-pixel tile one pair (16 wide).
+bool sconv_pools(int H, int W, int M) { return (W == 4 || W == 8 || W == 16) && H % 2 == 0 && M >= 16; }
+
 // True when the few-pixel kernel is the better choice for a bf16 3x3 layer of M pixels and N output
 // channels: a pixel-tiled kernel would run fewer than 64 workgroups.
 bool sconv_applies(const IgemmArgs& a) {
-  if (a.mode != G_3x3 || a.epi == E_SHUFFLE_BIAS || a.pool != nullptr) return false;
+  if (a.mode != G_3x3 || a.epi == E_SHUFFLE_BIAS) return false;
+  if (a.pool != nullptr && !sconv_pools(a.Hi, a.Wi, a.M)) return false;
   if (a.Hi != a.Ho || a.Wi != a.Wo || a.Cin % 32 != 0) return false;
   if ((int64_t)a.M * a.N >= (64 << 13)) return false;              // 64 tiles of 256 pixels x 32 channels
   // byte offsets are 32-bit inside the kernel
@@ -208,6 +265,9 @@ int launch_sconv_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
   a.N = g.N; a.bias = g.epi == E_PLAIN ? nullptr : g.bias; a.n_real = g.n_real; a.relu = g.epi == E_BIAS_RELU;
   a.out = g.out; a.out_cs = g.out_cs; a.out_co = g.out_co;
   a.mask = g.mask; a.mask_cs = g.mask_cs; a.mask_co = g.mask_co;
+  a.pool = g.pool; a.pool_cs = g.pool_cs; a.pool_co = g.pool_co;
+  MI_REQUIRE(g.pool == nullptr || (g.mask == nullptr && sconv_pools(g.Hi, g.Wi, g.M) && g.pool_cs % 16 == 0 && g.pool_co % 16 == 0 && ((uintptr_t)g.pool & 15) == 0),
+             "sconv: the pooled output cannot be fused for this shape");
   a.H = g.Hi; a.W = g.Wi; a.M = g.M;
   a.chunks = g.Cin / 32; a.units = 9 * a.chunks;
   a.d_hw = make_fastdiv((uint32_t)(g.Hi * g.Wi)); a.d_w = make_fastdiv((uint32_t)g.Wi);
@@ -215,7 +275,9 @@ int launch_sconv_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
   // workgroup tile: 16 pixels for a single tiny image; 32 pixels x 16 channels while that gives at
   // most 256 workgroups (their number matters most); 32 x 32, a third less operand traffic per
   // MFMA, beyond that
-  const int shape = g.M <= 16 ? 0 : ((int64_t)(g.N / 16) * ((g.M + 31) / 32) <= 256 || g.N % 32 != 0) ? 1 : 2;
+  const bool pool16 = g.pool != nullptr && g.Wi == 16;      // a row pair of a 16-wide image needs both fragments of a 32-pixel tile
+  const int shape = (!pool16 && (int64_t)(g.N / 16) * ((g.M + 15) / 16) <= 256) ? 0
+                    : ((int64_t)(g.N / 16) * ((g.M + 31) / 32) <= 256 || g.N % 32 != 0) ? 1 : 2;
   const int pix = shape == 0 ? 16 : 32, chn = shape == 2 ? 32 : 16;
   const dim3 tiles2(g.N / chn, (g.M + pix - 1) / pix);
   const int tiles = (int)(tiles2.x * tiles2.y);
