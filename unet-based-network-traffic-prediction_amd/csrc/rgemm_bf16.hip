@@ -48,6 +48,29 @@ __global__ __launch_bounds__(64 * KW) void rgemm_kernel(const RgemmArgs ra) {
   const int n0 = blockIdx.x * 64, m0 = blockIdx.y * (16 * PF);
   const int HW = a.Ho * a.Wo;
 
+  unsigned wbase[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n0 + 16 * (r16 >> 2) + 4 * t + (r16 & 3);
+    wbase[t] = ((unsigned)n * (unsigned)a.Kp + (unsigned)ch * 8u) * 2u;
+  }
+  const __amdgpu_buffer_rsrc_t rin = rg_rsrc(a.in), rw = rg_rsrc(a.w);
+
+  const int s0 = wave * ra.spw;
+  const int s1 = s0 + ra.spw < ra.slabs ? s0 + ra.spw : ra.slabs;
+
+  // the weights of the first batch are asked for before the pixel geometry is worked out: they are the
+  // operand that comes from far away (read once per layer; the few pixels are read by every workgroup)
+  bf16x8_t wf[U][TN];
+  auto load_weights = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < U; ++i)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) wf[i][t] = rg_frag(rw, s + i < s1 ? wbase[t] + (unsigned)((s + i) * 32) * 2u : kROob);
+  };
+  load_weights(s0);
+  __builtin_amdgcn_sched_barrier(0);
+
   // this lane's pixel of each fragment: operand byte offset, and the pixel (2y, 2x) of the 2Ho x 2Wo image
   unsigned pbase[PF];
   int64_t up[PF];
@@ -65,23 +88,13 @@ __global__ __launch_bounds__(64 * KW) void rgemm_kernel(const RgemmArgs ra) {
     const uint32_t src_pix = MODE == G_1x1 ? pc : (uint32_t)up[j];
     pbase[j] = (src_pix * (uint32_t)a.in_cs + (uint32_t)a.in_co + (uint32_t)ch * 8u) * 2u;
   }
-  unsigned wbase[TN];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int n = n0 + 16 * (r16 >> 2) + 4 * t + (r16 & 3);
-    wbase[t] = ((unsigned)n * (unsigned)a.Kp + (unsigned)ch * 8u) * 2u;
-  }
-  const __amdgpu_buffer_rsrc_t rin = rg_rsrc(a.in), rw = rg_rsrc(a.w);
-
-  const int s0 = wave * ra.spw;
-  const int s1 = s0 + ra.spw < ra.slabs ? s0 + ra.spw : ra.slabs;
 
   f32x4_t acc[TN * PF];
 #pragma unroll
   for (int j = 0; j < TN * PF; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   for (int s = s0; s < s1; s += U) {
-    bf16x8_t wf[U][TN], pf[U][PF];
+    bf16x8_t pf[U][PF];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const bool on = s + i < s1;
@@ -95,8 +108,6 @@ __global__ __launch_bounds__(64 * KW) void rgemm_kernel(const RgemmArgs ra) {
         poff = (unsigned)(((tap >> 1) * (2 * a.Wo) + (tap & 1)) * a.in_cs + c) * 2u;
       }
 #pragma unroll
-      for (int t = 0; t < TN; ++t) wf[i][t] = rg_frag(rw, on ? wbase[t] + (unsigned)k * 2u : kROob);
-#pragma unroll
       for (int j = 0; j < PF; ++j) pf[i][j] = rg_frag(rin, (on && live[j]) ? pbase[j] + poff : kROob);
     }
     __builtin_amdgcn_sched_barrier(0);      // every load of the batch is issued before the first MFMA waits
@@ -106,6 +117,10 @@ __global__ __launch_bounds__(64 * KW) void rgemm_kernel(const RgemmArgs ra) {
       for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int j = 0; j < PF; ++j) acc[t * PF + j] = mma_slab(wf[i][t], pf[i][j], acc[t * PF + j]);
+    if (s + U < s1) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_weights(s + U);
+    }
   }
 
   if (KW > 1) {     // the K waves combine in wave order
@@ -209,8 +224,9 @@ int launch_rgemm_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
   while (kw < 8 && ra.slabs / (2 * kw) >= 4) kw *= 2;
   ra.spw = (ra.slabs + kw - 1) / kw;
   const bool fwd = g.mode == G_1x1;
-  // pixel tile: 32; 16 for a single tiny image
-  const int pf = g.M <= 16 ? 1 : 2;
+  // pixel tile: 16 while that gives at most 256 workgroups (their number matters most: a CU has only so many
+  // loads in flight), else 32
+  const int pf = (int64_t)(g.N / 64) * ((g.M + 15) / 16) <= 256 ? 1 : 2;
   const dim3 grid(g.N / 64, (g.M + 16 * pf - 1) / (16 * pf));
   static const char* const names[2][4] = {{"rgemm_fwd_k1", "rgemm_fwd_k2", "rgemm_fwd_k4", "rgemm_fwd_k8"},
                                           {"rgemm_dgrad_k1", "rgemm_dgrad_k2", "rgemm_dgrad_k4", "rgemm_dgrad_k8"}};
