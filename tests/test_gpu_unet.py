@@ -191,7 +191,9 @@ def test_narrow_input_pixels_and_a_poisoned_workspace(ua, cin, feats, B, H, W, d
     # a gradient tensor by a quarter of its norm.)
     (1, 1, (8,), 48, 8, 8), (3, 2, (6, 12), 1, 12, 20), (12, 1, (16, 32, 64, 128, 256), 2, 32, 32),
     (5, 7, (4, 8, 16, 32, 64, 128), 2, 64, 64), (2, 16, (24, 48), 5, 10, 6), (12, 12, (32, 64), 1, 17, 23),
-    (7, 3, (20, 40, 80), 2, 36, 28)])
+    (7, 3, (20, 40, 80), 2, 36, 28),
+    # 64 channels on 8x4 images, 1280 pixels: the few-pixel conv kernel pools 32-pixel tiles of 4-wide images
+    (12, 1, (32, 64), 40, 16, 8)])
 def test_architecture_variants_against_oracle(ua, arch, dtype):
     """The constructor's whole argument space (models/unet2d.py:9-15), not only the benched widths:
     prediction, every parameter gradient and the input gradient against the CPU oracle."""
@@ -213,6 +215,12 @@ def test_architecture_variants_against_oracle(ua, arch, dtype):
     errs = {k: rel(p.grad.cpu(), pgrads[k]) for k, p in model.named_parameters()}
     assert max(errs.values()) < bar["grad"], sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert rel(Xg.grad.cpu(), dX) < bar["grad"]
+    # the max-pool, wherever it ran (own launch or a conv's epilogue), is exact given the tensor it pools
+    names = model.last_plan.tensors()
+    for l in range(len(feats)):
+        if "act.pool.%d" % l in names and "act.downs.%d.3" % l in names:
+            src = model.workspace_tensor("act.downs.%d.3" % l)
+            assert torch.equal(model.workspace_tensor("act.pool.%d" % l), torch.nn.functional.max_pool2d(src, 2)), l
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
