@@ -1037,3 +1037,33 @@ def test_k_split_across_workgroups_is_repeatable_and_leaves_its_counters_at_zero
             assert rel(other(X), first[(i, 1.0)]) < 2e-3, i
     ref = O.unet_forward(state, Xs[0].cpu())
     assert rel(first[(0, 1.0)].cpu(), ref) < BAR["bf16"]["out"]
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_few_pixel_conv_pools_behind_a_k_split(ua, B):
+    """A 5-level net on one or two 128x128 matrices: the deepest encoder conv (512 -> 512 channels on 8x8
+    images, K = 4608) runs on the few-pixel kernel, with one image also split in K across workgroups, and
+    writes the 2x2 max-pool of its output itself -- only the workgroup that arrives last holds the sums.
+    Every pooled tensor must equal the max-pool of the tensor it was taken from, bit for bit, twice in a row
+    (the second pass finds the arrival counters where the first left them), and the prediction the oracle's."""
+    import ctypes as C
+    feats = (32, 64, 128, 256, 512)
+    state = O.init_state_dict(12, 1, feats, seed=2)
+    model = ua.UNet(12, 1, feats, compute_dtype="bf16")
+    model.load_state_dict(state)
+    model = model.to("cuda").eval()
+    X = O.synthetic_batch(B, 12, 1, 128, 128, seed=31)[0]
+    with torch.no_grad():
+        for rnd in range(2):
+            pred = model(X.cuda())
+            names = model.last_plan.tensors()
+            for l in range(len(feats)):
+                src = model.workspace_tensor("act.downs.%d.3" % l)
+                assert torch.equal(model.workspace_tensor("act.pool.%d" % l), torch.nn.functional.max_pool2d(src, 2)), (rnd, l)
+            assert "act.pool.4" in names
+    if B == 1:
+        off, cb, tot = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        assert ua.lib().mi_unet_plan_ksplit_region(model.last_plan.handle, C.byref(off), C.byref(cb), C.byref(tot)) == 0
+        assert tot.value > cb.value > 0, "this shape was expected to carry K-split scratch"
+        assert int(model.last_plan.ws[off.value: off.value + cb.value].to(torch.int32).abs().sum().item()) == 0
+    assert rel(pred.cpu(), O.unet_forward(state, X)) < BAR["bf16"]["out"]
