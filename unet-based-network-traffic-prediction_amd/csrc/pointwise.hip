@@ -934,12 +934,12 @@ __global__ __launch_bounds__(256) void head_bwd_quad_kernel(const T* __restrict_
 // eight threads per pixel exchanging dpred by lane shuffles, and four pixels in flight per thread;
 // the strided dpred planes, not latency, bound this kernel.)
 template <typename T, int COUTP>
-__global__ __launch_bounds__(256) void head_bwd_mid_kernel(const T* __restrict__ x, int xcs, int xco,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COUTP <= 12 ? 3 : 2, COUTP <= 12 ? 3 : 2))) void head_bwd_mid_kernel(const T* __restrict__ x, int xcs, int xco,
                                                             const float* __restrict__ w, const float* __restrict__ dpred,
                                                             T* __restrict__ dx, int dcs, int dco, float* __restrict__ part,
-                                                            int64_t npix, int HW, int Cin, int Cout, int relu_mask) {
+                                                            uint32_t npix, int HW, FastDiv dHW, int Cin, int Cout, int relu_mask) {
   constexpr int CP = 32;
-  __shared__ float sw[COUTP * CP];
+  __shared__ __attribute__((aligned(16))) float sw[COUTP * CP];
   __shared__ float red[4][COUTP * CP + COUTP];
   for (int i = threadIdx.x; i < COUTP * CP; i += 256) {
     const int co = i / CP, c = i % CP;
@@ -955,33 +955,49 @@ __global__ __launch_bounds__(256) void head_bwd_mid_kernel(const T* __restrict__
     for (int q = 0; q < 8; ++q) acc[co][q] = 0.f;
   }
   constexpr int N = Vec16<T>::N;
-  for (int64_t p = blockIdx.x * 64ll + (threadIdx.x >> 2); p < npix; p += (int64_t)gridDim.x * 64) {
-    const uint32_t b = (uint32_t)p / (uint32_t)HW, r = (uint32_t)p - b * (uint32_t)HW;
+  // dpred is read through a buffer resource: one 32-bit offset per pixel in a register, the channel plane as a
+  // wave-uniform offset (the launcher checks that the tensor is below 2 GiB); as 64-bit pointers the COUTP plane
+  // addresses and their loop-invariant parts took two dozen registers
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dpred), 0, 0x7fffffff, 0x00020000);
+  for (uint32_t p = blockIdx.x * 64u + (threadIdx.x >> 2); p < npix; p += gridDim.x * 64u) {
+    const uint32_t b = fdiv(p, dHW), r = p - b * (uint32_t)HW;
+    const uint32_t goff = (b * (uint32_t)(Cout * HW) + r) * 4u;
     float g[COUTP];
 #pragma unroll
-    for (int co = 0; co < COUTP; ++co) {                // clamped address, then select: all loads in flight
-      const float v = dpred[((int64_t)b * Cout + (co < Cout ? co : 0)) * HW + r];
+    for (int co = 0; co < COUTP; ++co) {                // clamped plane, then select: all loads in flight
+      const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)goff, (co < Cout ? co : 0) * HW * 4, 0));
       g[co] = co < Cout ? v : 0.f;
       accb[co] += g[co];
     }
     float xv[8], d[8];
 #pragma unroll
-    for (int c = 0; c < 8; c += N) Vec16<T>::load(x + p * xcs + xco + cg * 8 + c, xv + c);
+    for (int c = 0; c < 8; c += N) Vec16<T>::load(x + (int64_t)p * xcs + xco + cg * 8 + c, xv + c);
 #pragma unroll
     for (int q = 0; q < 8; ++q) d[q] = 0.f;
+    // The weights are read from LDS in every iteration (two 16-byte broadcast reads per output channel), through an
+    // offset the compiler cannot see through: hoisted out of the loop they take COUTP x 8 registers next to the COUTP x 8
+    // accumulators, which left ONE wave per SIMD to cover the latency of thirteen loads per pixel.
+    int woff = cg * 8;
 #pragma unroll
-    for (int co = 0; co < COUTP; ++co)
+    for (int co = 0; co < COUTP; ++co) {
+      // every second channel the offset passes through an empty statement together with a running sum: the reads
+      // of the next two channels cannot be issued before the sums of the last two exist (left alone, all 2 x COUTP
+      // reads are issued first, into registers that are not there)
+      if (co % 2 == 0) asm volatile("" : "+v"(woff), "+v"(d[0]));
+      const f32x4_t* swv = (const f32x4_t*)(sw + woff);
+      const f32x4_t w0 = swv[co * (CP / 4)], w1 = swv[co * (CP / 4) + 1];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        d[q] = fmaf(g[co], sw[co * CP + cg * 8 + q], d[q]);
+        d[q] = fmaf(g[co], q < 4 ? w0[q & 3] : w1[q & 3], d[q]);
         acc[co][q] = fmaf(g[co], xv[q], acc[co][q]);
       }
+    }
     if (relu_mask) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) d[q] = xv[q] > 0.f ? d[q] : 0.f;
     }
 #pragma unroll
-    for (int c = 0; c < 8; c += N) Vec16<T>::store(dx + p * dcs + dco + cg * 8 + c, d + c);
+    for (int c = 0; c < 8; c += N) Vec16<T>::store(dx + (int64_t)p * dcs + dco + cg * 8 + c, d + c);
   }
   // lanes with equal (lane & 3) hold the same channel group: butterfly over the other lane bits
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1026,7 +1042,8 @@ __global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restri
     *o = alpha * s + (beta != 0.f ? beta * *o : 0.f);
   }
 }
-constexpr int kHeadBlocks = 512;
+constexpr int kHeadBlocks = 768;          // partial-sum slots in the workspace; the mid kernel runs three workgroups per CU
+constexpr int kHeadBlocksSmall = 512;     // the other variants: two per CU
 size_t head_ws_bytes(int Cin, int Cout) { return (size_t)kHeadBlocks * (Cout * pad_ch(Cin) + Cout) * sizeof(float); }
 int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float* dpred, void* dx, int dcs, int dco,
                     float* dW, float* db, float alpha, float beta, void* ws, size_t ws_bytes, int B, int H, int W,
@@ -1037,10 +1054,10 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
   const int64_t npix = (int64_t)B * H * W;
   MI_REQUIRE(npix < (1ll << 31), "head: pixel count out of range");
   const int64_t ntiles = (npix + kHeadTile - 1) / kHeadTile;
-  const int nblocks = (int)(ntiles < kHeadBlocks ? ntiles : kHeadBlocks);
+  const int nblocks = (int)(ntiles < kHeadBlocksSmall ? ntiles : kHeadBlocksSmall);
   if (Cout <= 2 && Cp == 32) {
     int nb = (int)((npix * (dtype == MI_BF16 ? 4 : 8) / 4 + 255) / 256);      // four pixels in flight per lane
-    if (nb > kHeadBlocks) nb = kHeadBlocks;
+    if (nb > kHeadBlocksSmall) nb = kHeadBlocksSmall;
     if (nb < 1) nb = 1;
 #define HEAD_SMALL(TT, CO, CPV)                                                                                   \
     hipLaunchKernelGGL((head_bwd_quad_kernel<TT, CO>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred, \
@@ -1057,12 +1074,12 @@ int launch_head_bwd(const void* x, int xcs, int xco, const float* w, const float
     hipLaunchKernelGGL(head_finalize_kernel, dim3(np2), dim3(64), 0, s, (const float*)ws, nb, Cin, Cp, Cout, dW, db, alpha, beta);
     return check_hip(hipGetLastError(), "head_finalize");
   }
-  if (Cp == 32) {
+  if (Cp == 32 && npix * Cout * 4 < (1ll << 31)) {
     int nb = (int)((npix + 63) / 64);
     if (nb > kHeadBlocks) nb = kHeadBlocks;
 #define HEAD_MID(TT, COP)                                                                                          \
     hipLaunchKernelGGL((head_bwd_mid_kernel<TT, COP>), dim3(nb), dim3(256), 0, s, (const TT*)x, xcs, xco, w, dpred,   \
-                       (TT*)dx, dcs, dco, (float*)ws, npix, H * W, Cin, Cout, relu_mask)
+                       (TT*)dx, dcs, dco, (float*)ws, (uint32_t)npix, H * W, make_fastdiv(H * W), Cin, Cout, relu_mask)
     if (dtype == MI_BF16) {
       if (Cout <= 4) HEAD_MID(__bf16, 4); else if (Cout <= 8) HEAD_MID(__bf16, 8); else if (Cout <= 12) HEAD_MID(__bf16, 12); else HEAD_MID(__bf16, 16);
     } else {
