@@ -9,11 +9,11 @@ python - <<PY
 import csv, glob
 f = glob.glob("$out/infer_trace_b$b/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-23*40:]
+rows = rows[-23*40:]      # the last forty forward passes
 import collections
 dur = collections.defaultdict(list); gap = collections.defaultdict(list)
 for a, b in zip(rows, rows[1:]):
-    n = b["Kernel_Name"].split("(")[0][:60]
+    n = b["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]
     dur[n].append(int(b["End_Timestamp"]) - int(b["Start_Timestamp"]))
     gap[n].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
 tot = 0
