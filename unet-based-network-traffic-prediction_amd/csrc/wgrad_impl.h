@@ -47,6 +47,11 @@ template <> __device__ __forceinline__ int tile_off<__bf16>(int r, int q) {
 template <> __device__ __forceinline__ int tile_off<float>(int r, int q) {
   return r * 256 + (((((q >> 2) ^ (r & 1)) << 2) | (q & 3)) << 4);
 }
+// fp32 tiles of 32 or 128 channels per row (the 32 x 128 output tile below): the same rule, the 64-byte
+// column group XORed with bit 0 of the row (rows 128 bytes apart never share a bank; 512 apart always would)
+template <int ROWB> __device__ __forceinline__ int tile_off_f32(int r, int q) {
+  return r * ROWB + (((((q >> 2) ^ (r & 1)) << 2) | (q & 3)) << 4);
+}
 
 // Fragment of tile column block `ct` (16 channels) for the MFMA k-step `ks`.
 // bf16: k-step = 32 pixels; lane (g = lane>>4, i = lane&15) ends up with channel ct*16+i of
@@ -68,6 +73,10 @@ __device__ __forceinline__ bf16x8_t read_frag_tr(const char* tile, int ks, int c
 __device__ __forceinline__ float read_frag_tr(const char* tile, int ks, int ct, int lane, float) {
   const int r = ks * 4 + (lane >> 4), c = ct * 16 + (lane & 15);
   return *(const float*)(tile + tile_off<float>(r, c >> 2) + (c & 3) * 4);
+}
+template <int ROWB> __device__ __forceinline__ float read_frag_f32(const char* tile, int ks, int ct, int lane) {
+  const int r = ks * 4 + (lane >> 4), c = ct * 16 + (lane & 15);
+  return *(const float*)(tile + tile_off_f32<ROWB>(r, c >> 2) + (c & 3) * 4);
 }
 
 __device__ __forceinline__ f32x4_t mma_px(const bf16x8_t& a, const bf16x8_t& b, f32x4_t acc) {
@@ -314,10 +323,172 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// fp32 3x3 layers with at most 32 output channels (level 0 of the U-Net): a 32(n) x 128(k) output tile.  The 64 x 64
+// tile of the kernel above is half padding there -- half of its dy tile is read from the zero page and half of its
+// MFMAs multiply zeros.  Same staging, same fragment reads, same fixed-order partials; the four waves sit side by
+// side along k, and the two operand tiles have rows of 128 and 512 bytes.
+template <typename F>      // (F = float; a template so that every translation unit may include this header)
+__global__ __launch_bounds__(256, 2) void wgrad_n32_kernel(const WgradArgs a) {
+  static_assert(std::is_same<F, float>::value, "fp32 only");
+  constexpr int PB = 64, NT = 32, KT = 128;
+  constexpr int ROWB_A = NT * 4, ROWB_B = KT * 4;
+  constexpr int TILE_A = PB * ROWB_A, TILE_B = PB * ROWB_B, STAGE = TILE_A + TILE_B;
+  constexpr int KSTEPS = PB / 4;
+  constexpr int IT_A = PB * (NT / 4) / 256, IT_B = PB * (KT / 4) / 256;     // 16-byte chunks per thread per stage: 2 and 8
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wc = t >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int unit = (slot / a.usize) * 8 + xcd, mem = slot % a.usize;
+  if (unit >= a.units) return;
+  const int z = unit, by = mem;                 // one n-block: a unit is a whole pixel split
+  const int k0 = by * KT;
+  const int K = a.taps * a.Cb;
+  const float* __restrict__ pa = (const float*)a.a;
+  const float* __restrict__ pb = (const float*)a.b;
+  const int HW = a.Ho * a.Wo;
+  const int64_t zoff_a = ((intptr_t)a.zero - (intptr_t)a.a) / 4;
+  const int64_t zoff_b = ((intptr_t)a.zero - (intptr_t)a.b) / 4;
+  const int pbeg = z * a.pix_per_split;
+  const int pend = min(a.M, pbeg + a.pix_per_split);
+
+  const int cch_a = t % (NT / 4), rowa0 = t / (NT / 4);
+  const int an = cch_a * 4;
+  const bool a_ok = an < a.Na;
+  const int cch_b = t % (KT / 4), rowb0 = t / (KT / 4);
+  const int bk = k0 + cch_b * 4;
+  const int btap = bk / a.Cb, bc = bk - btap * a.Cb;
+  const bool b_ok = bk < K;
+  const int ty = btap / 3, dy = ty - 1, dx = btap - ty * 3 - 1;
+  const int64_t toff = (int64_t)(dy * a.Wb + dx) * a.b_cs + a.b_co + bc;
+
+  u32x4_t ra[IT_A], rb[IT_B];
+  auto load_stage = [&](int pstage) {
+#pragma unroll
+    for (int i = 0; i < IT_A; ++i) {
+      const int p = pstage + rowa0 + i * (256 / (NT / 4));
+      const int64_t oa = (p < pend && a_ok) ? (int64_t)p * a.a_cs + a.a_co + an : zoff_a;
+      ra[i] = *(const u32x4_t*)(pa + opaque_offset(oa));
+    }
+#pragma unroll
+    for (int i = 0; i < IT_B; ++i) {
+      const int p = pstage + rowb0 + i * (256 / (KT / 4));
+      const bool pv = p < pend;
+      const uint32_t pc = pv ? (uint32_t)p : 0u;
+      const uint32_t r = pc - fdiv(pc, a.divHW) * (uint32_t)HW;
+      const uint32_t y = fdiv(r, a.divW), x = r - y * (uint32_t)a.Wo;
+      const bool bv = pv && b_ok && (unsigned)((int)y + dy) < (unsigned)a.Hb && (unsigned)((int)x + dx) < (unsigned)a.Wb;
+      const int64_t ob = bv ? (int64_t)p * a.b_cs + toff : zoff_b;
+      rb[i] = *(const u32x4_t*)(pb + opaque_offset(ob));
+    }
+  };
+  auto store_stage = [&](int buf) {
+    char* At = smem + buf * STAGE;
+    char* Bt = At + TILE_A;
+#pragma unroll
+    for (int i = 0; i < IT_A; ++i) *(u32x4_t*)(At + tile_off_f32<ROWB_A>(rowa0 + i * (256 / (NT / 4)), cch_a)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < IT_B; ++i) *(u32x4_t*)(Bt + tile_off_f32<ROWB_B>(rowb0 + i * (256 / (KT / 4)), cch_b)) = rb[i];
+  };
+
+  f32x4_t acc[2][2], accr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    accr[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_rows = a.rowsum != nullptr && by == 0 && wc == 0;
+
+  // the fragments of step ks+1 are read under the MFMAs of step ks (two register sets, order spelled out)
+  auto compute_t = [&](int buf, auto rows_c) {
+    constexpr bool ROWS = decltype(rows_c)::value;
+    const char* At = smem + buf * STAGE;
+    const char* Bt = At + TILE_A;
+    float fa[2][2], fb[2][2];
+    auto read_step = [&](int ks, int set) {
+      fa[set][0] = read_frag_f32<ROWB_A>(At, ks, 0, lane);
+      fa[set][1] = read_frag_f32<ROWB_A>(At, ks, 1, lane);
+      fb[set][0] = read_frag_f32<ROWB_B>(Bt, ks, 2 * wc, lane);
+      fb[set][1] = read_frag_f32<ROWB_B>(Bt, ks, 2 * wc + 1, lane);
+    };
+    constexpr int NM = 4 + (ROWS ? 2 : 0);
+    read_step(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int c = ks & 1;
+      if (ks + 1 < KSTEPS) read_step(ks + 1, c ^ 1);
+      acc[0][0] = mma_px(fb[c][0], fa[c][0], acc[0][0]);
+      acc[0][1] = mma_px(fb[c][1], fa[c][0], acc[0][1]);
+      acc[1][0] = mma_px(fb[c][0], fa[c][1], acc[1][0]);
+      acc[1][1] = mma_px(fb[c][1], fa[c][1], acc[1][1]);
+      if (ROWS) {
+        accr[0] = mma_px(fa[c][0], 1.0f, accr[0]);
+        accr[1] = mma_px(fa[c][1], 1.0f, accr[1]);
+      }
+      if (ks + 1 < KSTEPS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if (NM > 4) __builtin_amdgcn_sched_group_barrier(0x008, NM - 4, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      }
+    }
+  };
+
+  const int nst = (pend - pbeg + PB - 1) / PB;
+  if (nst > 0) {
+    load_stage(pbeg);
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      const bool more = st + 1 < nst;
+      if (more) load_stage(pbeg + (st + 1) * PB);
+      if (do_rows) compute_t(st & 1, std::true_type{}); else compute_t(st & 1, std::false_type{});
+      if (more) store_stage((st + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // D layout as above: row (= k) = 4*(lane>>4) + q, col (= n) = lane & 15
+  const int rq = 4 * (lane >> 4), cq = lane & 15;
+  float* part = a.part + (int64_t)z * a.Na * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + (2 * wc + j) * 16 + rq;
+      const int n = i * 16 + cq;
+      if (n < a.Na && k < K) *(f32x4_t*)(part + (int64_t)n * K + k) = acc[i][j];
+    }
+  if (do_rows && cq == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = i * 16 + rq + q;
+        if (n < a.Na) a.rowsum[(int64_t)z * a.Na + n] = accr[i][q];
+      }
+  }
+}
+
 template <typename T>
 static int launch_wgrad_t(const WgradArgs& a_in, hipStream_t s, const char** name) {
   WgradArgs a = a_in;
   const int K = a.taps * a.Cb;
+  if constexpr (std::is_same<T, float>::value) {
+    if (a.mode == G_3x3 && a.Na <= 32 && a.colsum == nullptr) {
+      a.gx = 1; a.gy = (K + 127) / 128;
+      a.usize = a.gy; a.units = a.splits;
+      if (name) *name = "wgrad_32x128";
+      hipLaunchKernelGGL(wgrad_n32_kernel<T>, dim3((a.units + 7) / 8 * 8 * a.usize), dim3(256), 0, s, a);
+      return check_hip(hipGetLastError(), "wgrad launch");
+    }
+  }
   a.gx = (a.Na + 63) / 64; a.gy = (K + 63) / 64;
   if (a.gx * a.gy <= 32) { a.usize = a.gx * a.gy; a.units = a.splits; }
   else { a.usize = a.gy; a.units = a.splits * a.gx; }
