@@ -226,6 +226,10 @@ int launch_wgrad(const WgradArgs& a_in, int dtype, hipStream_t s, const char** n
   MI_REQUIRE(a.splits >= 1 && a.pix_per_split % (dtype == MI_BF16 ? 128 : 64) == 0 &&
                  (int64_t)a.splits * a.pix_per_split >= a.M,
              "wgrad: bad pixel split");
+  // fp32 3x3 layers on images that tile into 128-pixel blocks, split accordingly: one staged halo tile serves all 9 taps
+  if (dtype == MI_F32 && a.mode == G_3x3 && a.colsum == nullptr && a.pix_per_split % 128 == 0 && a.Ho == a.Hb && a.Wo == a.Wb &&
+      hwgrad_f32_applies(a.B, a.Hb, a.Wb, a.Na, a.Cb, a.a_cs, a.b_cs))
+    return launch_hwgrad_f32(a, s, name);
   return dtype == MI_BF16 ? launch_wgrad_bf16(a, s, name) : launch_wgrad_f32(a, s, name);
 }
 
@@ -329,6 +333,9 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
   }
   l.posmajor = H * W <= 16 && Cp % 64 == 0;
   l.splits = wgrad_choose_splits(M, Np, K, dtype, &l.pps);
+  // fp32 on tiling images: the halo-tile kernel, with one round of workgroups (strides are checked again at the launch:
+  // a view too large for its 32-bit offsets falls back to the generic kernel with the same, valid, split)
+  if (dtype == MI_F32 && !l.posmajor && hwgrad_f32_applies(B, H, W, Np, Cp, 16, 16)) l.splits = hwgrad_f32_splits(B, H, W, Np, Cp, &l.pps);
   l.slabs = l.splits;
   l.part_bytes = (size_t)l.splits * Np * K * sizeof(float);
   l.sum_bytes = (size_t)l.splits * Np * sizeof(float);

@@ -154,6 +154,10 @@ struct Conv3WgradCall {
 struct HwgradBatch { HwgradArgs layer[2]; int n, wgs0; int xcd_order; int rot[2]; };
 int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const char** name);
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
+// fp32 halo-tile weight gradient of 3x3 layers (hwgrad_f32.hip): takes the generic kernel's arguments
+bool hwgrad_f32_applies(int B, int H, int W, int Na, int Cb, int a_cs, int b_cs);
+int hwgrad_f32_splits(int B, int H, int W, int Na, int Cb, int* pix_per_split);
+int launch_hwgrad_f32(const WgradArgs& a, hipStream_t s, const char** name);
 int launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s, const char** kernel_name = nullptr);
 // Fixed-order combination of the partials into dW / db, several layers per launch (the table is
 // passed by value in the kernel arguments).
