@@ -6,6 +6,6 @@ for i in 1 2; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']
-print('$lib'[:12], 'ms_per_step', d['ms_per_step'], {n: round(1e3*v['ms_per_step'],1) for n,v in k.items() if n.startswith('wgrad')})" || exit 1
+print('$lib'[:12], 'ms_per_step', d['ms_per_step'], {n: round(1e3*v['ms_per_step'],1) for n,v in k.items() if 'wgrad' in n})" || exit 1
   done
 done

@@ -331,11 +331,13 @@ WgradLayout conv3x3_wgrad_layout(int B, int H, int W, int Cin, int split, int Co
     l.sum_bytes = (size_t)l.slabs * Np * sizeof(float);
     return l;
   }
-  l.posmajor = H * W <= 16 && Cp % 64 == 0;
-  l.splits = wgrad_choose_splits(M, Np, K, dtype, &l.pps);
   // fp32 on tiling images: the halo-tile kernel, with one round of workgroups (strides are checked again at the launch:
-  // a view too large for its 32-bit offsets falls back to the generic kernel with the same, valid, split)
-  if (dtype == MI_F32 && !l.posmajor && hwgrad_f32_applies(B, H, W, Np, Cp, 16, 16)) l.splits = hwgrad_f32_splits(B, H, W, Np, Cp, &l.pps);
+  // a view too large for its 32-bit offsets falls back to the generic kernel with the same, valid, split).  It also takes
+  // the 4x4 images: all nine taps at 107 TFLOP/s beat the position-major walk over the 69 % of in-bounds products at 74-98.
+  const bool halo32 = dtype == MI_F32 && hwgrad_f32_applies(B, H, W, Np, Cp, 16, 16);
+  l.posmajor = H * W <= 16 && Cp % 64 == 0 && !halo32;
+  l.splits = wgrad_choose_splits(M, Np, K, dtype, &l.pps);
+  if (halo32) l.splits = hwgrad_f32_splits(B, H, W, Np, Cp, &l.pps);
   l.slabs = l.splits;
   l.part_bytes = (size_t)l.splits * Np * K * sizeof(float);
   l.sum_bytes = (size_t)l.splits * Np * sizeof(float);

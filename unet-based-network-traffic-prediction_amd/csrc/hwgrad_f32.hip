@@ -49,7 +49,7 @@ bool tiling(int H, int W, Geom* g) {
 
 struct Args {
   WgradArgs w;
-  int R, G, bands, HRt, Wp;
+  int R, G, bands, HRt, Wp, xcd_deal;
   FastDiv d_img, d_wp, d_rw, d_w, d_bands;     // halo rows per image, W+2, R*W, W, bands
 };
 
@@ -59,9 +59,15 @@ __global__ __launch_bounds__(512) void hwgrad_f32_kernel(const Args ha) {
   const WgradArgs& a = ha.w;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int gx = a.Na / 32, blocks = gx * (a.Cb / 32);
-  // id = slot*8 + xcd: the (n-block, c-block) workgroups of one pixel split sit on one XCD and share its L2
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int z = (slot / blocks) * 8 + xcd, mem = slot % blocks;
+  // id = slot*8 + xcd: the (n-block, c-block) workgroups of one pixel split sit on one XCD and share its L2 -- where
+  // there are at least 8 splits to deal and no XCD gets more workgroups than it has CUs; else the ids run split by split
+  int z, mem;
+  if (ha.xcd_deal) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    z = (slot / blocks) * 8 + xcd; mem = slot % blocks;
+  } else {
+    z = blockIdx.x / blocks; mem = blockIdx.x - z * blocks;
+  }
   if (z >= a.splits) return;
   const int by = mem / gx, bx = mem - by * gx;
   const int n0 = bx * 32, c0 = by * 32;
@@ -264,7 +270,9 @@ int launch_hwgrad_f32(const WgradArgs& w, hipStream_t s, const char** name) {
   ha.d_w = make_fastdiv(w.Wb); ha.d_bands = make_fastdiv(g.bands);
   const int blocks = (w.Na / 32) * (w.Cb / 32);
   if (name) *name = "hwgrad_f32_32x32x9";
-  hipLaunchKernelGGL(hwgrad_f32_kernel<0>, dim3((w.splits + 7) / 8 * 8 * blocks), dim3(512), 0, s, ha);
+  ha.xcd_deal = w.splits >= 8 && (w.splits + 7) / 8 * blocks <= 32;      // no XCD (32 CUs) is dealt a second round
+  const int grid = ha.xcd_deal ? (w.splits + 7) / 8 * 8 * blocks : w.splits * blocks;
+  hipLaunchKernelGGL(hwgrad_f32_kernel<0>, dim3(grid), dim3(512), 0, s, ha);
   return check_hip(hipGetLastError(), "hwgrad_f32 launch");
 }
 
