@@ -28,9 +28,9 @@ int launch_igemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
 int launch_hconv_f32(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_hconv_bf16(const HconvArgs& a, hipStream_t s, const char** name);
 int launch_dconv_bf16(const HconvArgs& a, hipStream_t s, const char** name, bool dry_run = false);
-bool sconv_applies(const IgemmArgs& a);
+bool sconv_applies(const IgemmArgs& a, int dtype);
 bool sconv_pools(int H, int W, int M);
-int launch_sconv_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
+int launch_sconv(const IgemmArgs& a, int dtype, hipStream_t s, const char** name);
 int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
 bool tconv_eligible(const IgemmArgs& a);
@@ -108,7 +108,7 @@ static bool hconv_args_for(const IgemmArgs& a, int dtype, HconvArgs* out) {
 // that takes two-tensor operands (IgemmArgs::in2 / out2).  Mirrors the dispatch of launch_igemm.
 bool conv3x3_takes_dconv(const IgemmArgs& a, int dtype) {
   // (a layer with the fused head never takes the few-pixel kernel: launch_igemm sends it here whatever its size)
-  if (dtype != MI_BF16 || (a.head_out == nullptr && sconv_applies(a))) return false;
+  if (dtype != MI_BF16 || (a.head_out == nullptr && sconv_applies(a, dtype))) return false;
   HconvArgs h{};
   if (!hconv_args_for(a, dtype, &h)) return false;
   if (a.pool != nullptr && !(a.mask == nullptr && a.Hi % 2 == 0 && a.Wi % 2 == 0 && h.R % 2 == 0)) return false;
@@ -143,7 +143,7 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
   MI_REQUIRE(!two_tensors || (dtype == MI_BF16 && a.in2_c0 % 32 == 0 && a.out2_n0 % 16 == 0 && aligned16(a.in2) && aligned16(a.out2)),
              "igemm: two-tensor operands need bf16 and 32-channel-aligned halves");
   // 3x3 layers of so few pixels that a pixel-tiled kernel would leave most CUs idle: K-split kernel
-  if (dtype == MI_BF16 && !two_tensors && sconv_applies(a)) return launch_sconv_bf16(a, s, name);
+  if (!two_tensors && sconv_applies(a, dtype)) return launch_sconv(a, dtype, s, name);
   // 3x3 stride-1 convolutions whose images tile evenly into 256-pixel blocks take the halo-tile
   // kernel (one LDS halo tile serves all 9 taps); everything else the generic gather kernel.
   {
@@ -189,7 +189,7 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
 bool conv3x3_fwd_fuses_pool(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
   const int M = B * H * W, ck = dtype == MI_BF16 ? 32 : 16;
   // few pixels (the test of sconv_applies): the K-split kernel pools 32-pixel tiles of narrow images
-  if (dtype == MI_BF16 && concat_cp(Cin, split) % 32 == 0 && (int64_t)M * pad_ch(Cout) < (64 << 13) && sconv_pools(H, W, M)) return true;
+  if (concat_cp(Cin, split) % (dtype == MI_BF16 ? 32 : 16) == 0 && (int64_t)M * pad_ch(Cout) < (64 << 13) && sconv_pools(H, W, M)) return true;
   int R, G, bands;
   if (M % 256 != 0 || concat_cp(Cin, split) % ck != 0 || !hconv_tiling(H, W, &R, &G, &bands) || !(G == 1 || B % G == 0))
     return false;

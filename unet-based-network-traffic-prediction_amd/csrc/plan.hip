@@ -666,13 +666,13 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
   cur += P->scratch_bytes;
   {
     // scratch for splitting K across workgroups: only when some level is small enough in pixels
-    // and wide enough in channels (K of 4096 and up) for the few-pixel conv kernel to use it
+    // and wide enough in channels (weight rows of 8 KiB and up) for the few-pixel conv kernel to use it
     bool any = false;
-    for (int l = 0; l <= L && d.dtype == MI_BF16; ++l) {
+    for (int l = 0; l <= L; ++l) {
       const int f = l < L ? d.features[l] : 2 * fb;
       const int64_t M = (int64_t)B * P->h[l] * P->w[l];
       const int kmax = 9 * (l < L ? 2 * pad_ch(f) : pad_ch(f));
-      if (M * pad_ch(l < L ? f : f / 2) < (64 << 13) && kmax >= 4096) any = true;
+      if (M * pad_ch(l < L ? f : f / 2) < (64 << 13) && kmax * (int)elem_size(d.dtype) >= 8192) any = true;
     }
     if (any) { P->ksplit_off = cur; P->ksplit_bytes = kKsplitBytes; cur += kKsplitBytes; }
   }

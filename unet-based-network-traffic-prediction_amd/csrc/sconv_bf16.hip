@@ -1,4 +1,4 @@
-// 3x3 convolution (forward and dgrad) for layers with FEW PIXELS: the deep levels of the U-Net of
+// 3x3 convolution (forward and dgrad, bf16 and fp32) for layers with FEW PIXELS: the deep levels of the U-Net of
 // models/unet2d.py:28-31 of the reference at batch sizes of one to a few images, where a layer is
 // a few hundred pixels against a megabyte or more of weights.
 //
@@ -26,7 +26,7 @@ struct SconvArgs {
   const void* mask; int mask_cs, mask_co;
   void* pool; int pool_cs, pool_co;     // optional: also write the 2x2 max-pool of the output (W of 4, 8 or 16; 32-pixel tiles)
   int H, W, M;
-  int chunks, units;                    // Cp/32, 9*chunks
+  int chunks, units;                    // Cp / (channels per unit: 32 in bf16, 16 in fp32), 9*chunks
   int ups, upw;                         // units per K split (blockIdx.z), units per wave within it
   int ksplit;                           // workgroups sharing one output tile
   float* part; unsigned* count;         // ksplit > 1: partial tiles [ksplit][tiles][..] and one arrival counter per tile
@@ -39,19 +39,24 @@ constexpr unsigned kOob = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sconv_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ bf16x8_t ld_frag(__amdgpu_buffer_rsrc_t r, unsigned off) {
+// A lane's 16 bytes are 8 (bf16) or 4 (fp32) consecutive k of one weight row / one pixel: the operand layout of one
+// v_mfma_f32_16x16x32_bf16, or of four v_mfma_f32_16x16x4_f32 (element j of every lane in the j-th; both operands
+// permute k the same way).  A unit of the K range is a tap's chunk of 32 (bf16) or 16 (fp32) channels.
+template <typename T> __device__ __forceinline__ typename ElemTraits<T>::frag_t ld_frag(__amdgpu_buffer_rsrc_t r, unsigned off) {
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  return __builtin_bit_cast(bf16x8_t, v);
+  return __builtin_bit_cast(typename ElemTraits<T>::frag_t, v);
 }
 
-template <int PF, int TN, int KW, int U>
+template <typename T, int PF, int TN, int KW, int U>
 __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
+  typedef typename ElemTraits<T>::frag_t frag_t;
+  constexpr unsigned EPC = ElemTraits<T>::EPC, UC = 4 * EPC, ESZ = sizeof(T);     // elements per lane, channels per unit
   __shared__ float red[KW - 1][TN * PF][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, ch = lane >> 4;
   const int n0 = blockIdx.x * (16 * TN), m0 = blockIdx.y * (16 * PF);
   const int HW = a.H * a.W;
 
-  const unsigned wbase = ((unsigned)(n0 + r16) * (unsigned)a.Kp + (unsigned)ch * 8u) * 2u;
+  const unsigned wbase = ((unsigned)(n0 + r16) * (unsigned)a.Kp + (unsigned)ch * EPC) * ESZ;
   const __amdgpu_buffer_rsrc_t rin = sconv_rsrc(a.in), rw = sconv_rsrc(a.w);
 
   const int z1 = ((int)blockIdx.z + 1) * a.ups < a.units ? ((int)blockIdx.z + 1) * a.ups : a.units;
@@ -61,14 +66,14 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
 
   // The weights of the first batch are asked for before anything else: their addresses need no pixel geometry,
   // and they are the loads that come from far away (a layer's weights are read once, its few pixels by every workgroup).
-  bf16x8_t wf[U][TN];
+  frag_t wf[U][TN];
   int wtap = tap, wc = c;
   auto load_weights = [&](int u) {
 #pragma unroll
     for (int i = 0; i < U; ++i) {
 #pragma unroll
       for (int t = 0; t < TN; ++t)
-        wf[i][t] = ld_frag(rw, u + i < u1 ? wbase + (unsigned)(t * 16 * a.Kp + wtap * a.Cp + wc * 32) * 2u : kOob);
+        wf[i][t] = ld_frag<T>(rw, u + i < u1 ? wbase + (unsigned)(t * 16 * a.Kp + wtap * a.Cp + wc * (int)UC) * ESZ : kOob);
       if (++wc == a.chunks) { wc = 0; ++wtap; }
     }
   };
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
       if (live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) vt |= 1u << t;
     }
     vtaps[j] = vt;
-    pbase[j] = (pc * (unsigned)a.in_cs + (unsigned)a.in_co + (unsigned)ch * 8u) * 2u;
+    pbase[j] = (pc * (unsigned)a.in_cs + (unsigned)a.in_co + (unsigned)ch * EPC) * ESZ;
   }
 
   f32x4_t acc[TN * PF];
@@ -99,15 +104,15 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
   for (int j = 0; j < TN * PF; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   for (int u = u0; u < u1; u += U) {
-    bf16x8_t pf[U][PF];
+    frag_t pf[U][PF];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const bool on = u + i < u1;
       const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;              // tap / 3, tap % 3 for tap < 9
-      const unsigned shift = (unsigned)(((ty - 1) * a.W + (tx - 1)) * a.in_cs + c * 32) * 2u;
+      const unsigned shift = (unsigned)(((ty - 1) * a.W + (tx - 1)) * a.in_cs + c * (int)UC) * ESZ;
 #pragma unroll
       for (int j = 0; j < PF; ++j)
-        pf[i][j] = ld_frag(rin, (on && ((vtaps[j] >> tap) & 1u)) ? pbase[j] + shift : kOob);
+        pf[i][j] = ld_frag<T>(rin, (on && ((vtaps[j] >> tap) & 1u)) ? pbase[j] + shift : kOob);
       if (++c == a.chunks) { c = 0; ++tap; }
     }
     __builtin_amdgcn_sched_barrier(0);      // every load of the batch is issued before the first MFMA waits
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
   }
 
   // lane holds channels n..n+3 (n = n0 + 16*t + 4*(lane>>4)) of pixel (lane&15) of each fragment
-  __bf16* __restrict__ out = (__bf16*)a.out;
-  const __bf16* __restrict__ mask = (const __bf16*)a.mask;
+  T* __restrict__ out = (T*)a.out;
+  const T* __restrict__ mask = (const T*)a.mask;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int n = n0 + 16 * t + 4 * ch;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64 * KW) void sconv_kernel(const SconvArgs a) {
     // maximum of the fp32 values rounds to the maximum of the stored ones.
     {
       if (a.pool != nullptr) {
-        __bf16* __restrict__ pool = (__bf16*)a.pool;
+        T* __restrict__ pool = (T*)a.pool;
         if (a.W == 16) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[0][q] = fmaxf(v[0][q], v[PF - 1][q]);
@@ -248,17 +253,18 @@ bool sconv_pools(int H, int W, int M) { return (W == 4 || W == 8 || W == 16) && 
 
 // True when the few-pixel kernel is the better choice for a bf16 3x3 layer of M pixels and N output
 // channels: a pixel-tiled kernel would run fewer than 64 workgroups.
-bool sconv_applies(const IgemmArgs& a) {
+bool sconv_applies(const IgemmArgs& a, int dtype) {
+  const int uc = dtype == MI_BF16 ? 32 : 16, esz = dtype == MI_BF16 ? 2 : 4;
   if (a.mode != G_3x3 || a.epi == E_SHUFFLE_BIAS) return false;
   if (a.pool != nullptr && !sconv_pools(a.Hi, a.Wi, a.M)) return false;
-  if (a.Hi != a.Ho || a.Wi != a.Wo || a.Cin % 32 != 0) return false;
+  if (a.Hi != a.Ho || a.Wi != a.Wo || a.Cin % uc != 0) return false;
   if ((int64_t)a.M * a.N >= (64 << 13)) return false;              // 64 tiles of 256 pixels x 32 channels
   // byte offsets are 32-bit inside the kernel
-  if ((int64_t)a.M * a.in_cs * 2 >= (1ll << 31) || (int64_t)a.N * a.Kp * 2 >= (1ll << 31)) return false;
+  if ((int64_t)a.M * a.in_cs * esz >= (1ll << 31) || (int64_t)a.N * a.Kp * esz >= (1ll << 31)) return false;
   return true;
 }
 
-int launch_sconv_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
+int launch_sconv(const IgemmArgs& g, int dtype, hipStream_t s, const char** name) {
   SconvArgs a{};
   a.in = g.in; a.in_cs = g.in_cs; a.in_co = g.in_co;
   a.w = g.w; a.Kp = g.Kp; a.Cp = g.Cin;
@@ -269,7 +275,7 @@ int launch_sconv_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
   MI_REQUIRE(g.pool == nullptr || (g.mask == nullptr && sconv_pools(g.Hi, g.Wi, g.M) && g.pool_cs % 16 == 0 && g.pool_co % 16 == 0 && ((uintptr_t)g.pool & 15) == 0),
              "sconv: the pooled output cannot be fused for this shape");
   a.H = g.Hi; a.W = g.Wi; a.M = g.M;
-  a.chunks = g.Cin / 32; a.units = 9 * a.chunks;
+  a.chunks = g.Cin / (dtype == MI_BF16 ? 32 : 16); a.units = 9 * a.chunks;
   a.d_hw = make_fastdiv((uint32_t)(g.Hi * g.Wi)); a.d_w = make_fastdiv((uint32_t)g.Wi);
   a.d_chunks = make_fastdiv((uint32_t)a.chunks);
   // workgroup tile: 16 pixels for a single tiny image; 32 pixels x 16 channels while that gives at
@@ -281,7 +287,7 @@ int launch_sconv_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
   const int pix = shape == 0 ? 16 : 32, chn = shape == 2 ? 32 : 16;
   const dim3 tiles2(g.N / chn, (g.M + pix - 1) / pix);
   const int tiles = (int)(tiles2.x * tiles2.y);
-  // With scratch memory from the caller, a long K range (4096 and up) is also split across
+  // With scratch memory from the caller, a long K range (8 KiB per weight row and up) is also split across
   // workgroups until about 256 of them run, each keeping at least 16 units: every CU then streams
   // a share of the weights.  Shorter ranges lose more to the exchange of partials than they gain.
   int ksplit = 1;
@@ -307,7 +313,11 @@ int launch_sconv_bf16(const IgemmArgs& g, hipStream_t s, const char** name) {
                                           {"sconv_32x32_k4", "sconv_32x32_k8", "sconv_32x32_k16"}};
   const int ki = kw == 16 ? 2 : kw == 8 ? 1 : 0;
   if (name) *name = names[shape][ki];
-#define SCONV_GO(PF, TN, KW, U) hipLaunchKernelGGL((sconv_kernel<PF, TN, KW, U>), grid, dim3(64 * KW), 0, s, a)
+#define SCONV_GO(PF, TN, KW, U)                                                                         \
+  do {                                                                                                  \
+    if (dtype == MI_BF16) hipLaunchKernelGGL((sconv_kernel<__bf16, PF, TN, KW, U>), grid, dim3(64 * KW), 0, s, a); \
+    else hipLaunchKernelGGL((sconv_kernel<float, PF, TN, KW, U>), grid, dim3(64 * KW), 0, s, a);          \
+  } while (0)
   if (shape == 0) {
     if (kw == 16) SCONV_GO(1, 1, 16, 9); else if (kw == 8) SCONV_GO(1, 1, 8, 9); else SCONV_GO(1, 1, 4, 9);
   } else if (shape == 1) {
