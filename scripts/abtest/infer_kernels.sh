@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel table (launches, us) of the 64x64 inference workload at one batch size: $1 = batch, $2 = library (optional)
 lib=${2:-unet-based-network-traffic-prediction_amd/libunet_tm_hip.so}
-timeout -k 10 200 python scripts/with_lib.py $lib bench.py --workload cfg5_infer64 --batch $1 --steps 300 --warmup 20 --no-cpu-baseline --profile-steps 50 2>/dev/null | python -c "
+timeout -k 10 200 python scripts/with_lib.py $lib bench.py --workload cfg5_infer64 ${DT:+--dtype $DT} --batch $1 --steps 300 --warmup 20 --no-cpu-baseline --profile-steps 50 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 n=sum(v['launches_per_step'] for v in d['kernels'].values())

@@ -189,7 +189,12 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
 bool conv3x3_fwd_fuses_pool(int B, int H, int W, int Cin, int split, int Cout, int dtype) {
   const int M = B * H * W, ck = dtype == MI_BF16 ? 32 : 16;
   // few pixels (the test of sconv_applies): the K-split kernel pools 32-pixel tiles of narrow images
-  if (concat_cp(Cin, split) % (dtype == MI_BF16 ? 32 : 16) == 0 && (int64_t)M * pad_ch(Cout) < (64 << 13) && sconv_pools(H, W, M)) return true;
+  if (concat_cp(Cin, split) % (dtype == MI_BF16 ? 32 : 16) == 0 && (int64_t)M * pad_ch(Cout) < sconv_limit(dtype, H * W)) {
+    if (sconv_pools(H, W, M)) return true;
+    // fp32: a fused pool would send the layer to the pixel-tiled kernel, which runs such a layer on a handful of
+    // workgroups (44 us against 5 + 4 for the few-pixel kernel and a pool launch); bf16 has the DMA-fed kernel for it
+    if (dtype == MI_F32) return false;
+  }
   int R, G, bands;
   if (M % 256 != 0 || concat_cp(Cin, split) % ck != 0 || !hconv_tiling(H, W, &R, &G, &bands) || !(G == 1 || B % G == 0))
     return false;

@@ -154,6 +154,10 @@ struct Conv3WgradCall {
 struct HwgradBatch { HwgradArgs layer[2]; int n, wgs0; int xcd_order; int rot[2]; };
 int launch_hwgrad_bf16(const HwgradArgs* layers, int n, hipStream_t s, const char** name);
 int wgrad_choose_splits(int M, int Na, int K, int dtype, int* pix_per_split);
+// A 3x3 layer of fewer than this many (pixels x output channels) takes the few-pixel kernel (sconv_bf16.hip).  fp32
+// goes four times further (its pixel-tiled kernel needs 31 us for one tile, whatever the layer) -- except on images of
+// at most 16 pixels, where a batch that large belongs to the position-major kernel.
+inline int64_t sconv_limit(int dtype, int HW) { return (dtype == MI_BF16 || HW <= 16) ? (64 << 13) : (64 << 15); }
 // fp32 halo-tile weight gradient of 3x3 layers (hwgrad_f32.hip): takes the generic kernel's arguments
 bool hwgrad_f32_applies(int B, int H, int W, int Na, int Cb, int a_cs, int b_cs);
 int hwgrad_f32_splits(int B, int H, int W, int Na, int Cb, int* pix_per_split);

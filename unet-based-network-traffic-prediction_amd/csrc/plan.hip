@@ -672,7 +672,7 @@ int mi_unet_plan_create(const mi_unet_desc* desc, mi_unet_plan** out) {
       const int f = l < L ? d.features[l] : 2 * fb;
       const int64_t M = (int64_t)B * P->h[l] * P->w[l];
       const int kmax = 9 * (l < L ? 2 * pad_ch(f) : pad_ch(f));
-      if (M * pad_ch(l < L ? f : f / 2) < (64 << 13) && kmax * (int)elem_size(d.dtype) >= 8192) any = true;
+      if (M * pad_ch(l < L ? f : f / 2) < sconv_limit(d.dtype, P->h[l] * P->w[l]) && kmax * (int)elem_size(d.dtype) >= 8192) any = true;
     }
     if (any) { P->ksplit_off = cur; P->ksplit_bytes = kKsplitBytes; cur += kKsplitBytes; }
   }

@@ -258,7 +258,7 @@ bool sconv_applies(const IgemmArgs& a, int dtype) {
   if (a.mode != G_3x3 || a.epi == E_SHUFFLE_BIAS) return false;
   if (a.pool != nullptr && !sconv_pools(a.Hi, a.Wi, a.M)) return false;
   if (a.Hi != a.Ho || a.Wi != a.Wo || a.Cin % uc != 0) return false;
-  if ((int64_t)a.M * a.N >= (64 << 13)) return false;              // 64 tiles of 256 pixels x 32 channels
+  if ((int64_t)a.M * a.N >= sconv_limit(dtype, a.Hi * a.Wi)) return false;     // bf16: 64 tiles of 256 pixels x 32 channels
   // byte offsets are 32-bit inside the kernel
   if ((int64_t)a.M * a.in_cs * esz >= (1ll << 31) || (int64_t)a.N * a.Kp * esz >= (1ll << 31)) return false;
   return true;
