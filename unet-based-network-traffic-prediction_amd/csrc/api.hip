@@ -35,8 +35,8 @@ int launch_pconv_f32(const PconvArgs& a, hipStream_t s, const char** name);
 int launch_pconv_bf16(const PconvArgs& a, hipStream_t s, const char** name);
 bool tconv_eligible(const IgemmArgs& a);
 int launch_tconv_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
-bool rgemm_eligible(const IgemmArgs& a);
-int launch_rgemm_bf16(const IgemmArgs& a, hipStream_t s, const char** name);
+bool rgemm_eligible(const IgemmArgs& a, int dtype);
+int launch_rgemm(const IgemmArgs& a, int dtype, hipStream_t s, const char** name);
 int launch_wgrad_f32(const WgradArgs& a, hipStream_t s, const char** name);
 int launch_wgrad_bf16(const WgradArgs& a, hipStream_t s, const char** name);
 
@@ -181,8 +181,8 @@ int launch_igemm(const IgemmArgs& a_in, int dtype, hipStream_t s, const char** n
   }
   // transposed convs with many pixels and a weight matrix that fits in LDS: streaming kernel
   if (dtype == MI_BF16 && tconv_eligible(a)) return launch_tconv_bf16(a, s, name);
-  // the other bf16 transposed convs (few pixels, long reductions): fragments straight from memory, K split over waves
-  if (dtype == MI_BF16 && rgemm_eligible(a) && (int64_t)a.M * a.N < (64 << 13)) return launch_rgemm_bf16(a, s, name);
+  // the other transposed convs of few pixels and long reductions (both dtypes): fragments straight from memory, K split over waves
+  if (rgemm_eligible(a, dtype) && (int64_t)a.M * a.N < (64 << 13)) return launch_rgemm(a, dtype, s, name);
   return dtype == MI_BF16 ? launch_igemm_bf16(a, s, name) : launch_igemm_f32(a, s, name);
 }
 
