@@ -25,5 +25,6 @@ run --workload cfg2_geant32_b512 --stock-optim
 run --workload cfg4_deep128_b64
 run --workload cfg5_infer64
 run --workload cfg5_infer64 --batch 1
+run --workload cfg5_infer64 --dtype fp32 --batch 1
 rm -f gpurun_out/.wl_line.json
 cat $out
