@@ -74,12 +74,13 @@ def test_conv3x3_1024_channels_fp32(ua, shape):
                                    (1, 256, 512, 4, 4, 0), (1, 64, 64, 4, 4, 0), (8, 128, 256, 8, 8, 0),
                                    (3, 64, 48, 8, 8, 0), (1, 32, 32, 5, 7, 0), (2, 96, 32, 16, 16, 0),
                                    (1, 64, 32, 32, 32, 32), (1, 512, 512, 4, 4, 0)])
-def test_conv3x3_few_pixels(ua, shape):
-    """bf16 layers of one to a few images at the deep levels (the shapes of a batch-1 forward of the
-    64x64 sweep): the K-split kernel for layers with few pixels, one and two pixel fragments per
-    workgroup, four and eight K waves, ragged pixel counts, padded channels, concat input, a chunk
-    count that is not a power of two."""
-    _check_conv3x3(ua, torch.bfloat16, shape)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_few_pixels(ua, dtype, shape):
+    """Layers of one to a few images at the deep levels (the shapes of a batch-1 forward of the
+    64x64 sweep), bf16 and fp32: the K-split kernel for layers with few pixels, one and two pixel
+    fragments per workgroup, four and eight K waves, ragged pixel counts, padded channels, concat
+    input, a chunk count that is not a power of two."""
+    _check_conv3x3(ua, dtype, shape)
 
 
 def _geometry_sweep():
