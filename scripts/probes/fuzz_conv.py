@@ -28,6 +28,15 @@ for i in range(n):
         print("FAIL", dtype, shape, type(e).__name__, str(e)[:200], flush=True)
         if not isinstance(e, AssertionError):
             traceback.print_exc()
+    # transposed conv 2x2 stride 2 on a related shape (the test function builds its own tensors from the shape)
+    tshape = (B, rng.choice([32, 64, 128, 256, 512]), rng.choice([16, 24, 32, 64, 128, 256]), max(1, H // 2), max(1, min(W, 32) // 2))
+    try:
+        T.test_convt2x2.__wrapped__(unet_amd, dtype, tshape) if hasattr(T.test_convt2x2, "__wrapped__") else T.test_convt2x2(unet_amd, dtype, tshape)
+    except Exception as e:                       # noqa: BLE001
+        bad += 1
+        print("FAIL convt", dtype, tshape, type(e).__name__, str(e)[:200], flush=True)
+        if not isinstance(e, AssertionError):
+            traceback.print_exc()
     if i % 20 == 19:
         print("..", i + 1, "cases,", bad, "failures", flush=True)
 print("done:", n, "cases,", bad, "failures")
